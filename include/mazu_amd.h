@@ -1,0 +1,191 @@
+/*
+ * mazu_amd.h -- C ABI of the MI355X-native SSHash k-mer -> unitig dictionary.
+ *
+ * This is the drop-in boundary for ONE path of COMBINE-lab/mazu: the `K2U`
+ * implementation `SSHash` (reference src/kphf/sshash.rs) behind the trait
+ * surface of src/kphf/mod.rs:58-140.  A Rust `impl K2U for GpuSSHash` binds
+ * exactly these symbols (INTEGRATION.md shows the stub).  Plain pointers and
+ * sizes only; no C++ or torch types.
+ *
+ * Conventions shared with the reference
+ *   - k-mer words: 2 bits per base, A=0 C=1 G=2 T=3, first base in the LSBs
+ *     (kmers crate / unitig_set.rs:226-229).  A query is the FORWARD word of a
+ *     CanonicalKmer (`km.get_fw_mer()`, sshash.rs:472); `km.swap()` == pass the
+ *     reverse complement.
+ *   - unitig_id = 0-based order of insertion (line order of .cf_seg,
+ *     unitig_set.rs:133-141); pos = 0-based offset of the k-mer's first base on
+ *     the stored strand of the unitig, for Identity and Twin alike
+ *     (kphf/mod.rs:79-98).
+ *   - every query entry point runs on the GPU.  There is no CPU fallback: with
+ *     no usable HIP device they return MZ_EHIP.
+ *
+ * Threading: an index is immutable after construction; all query entry points
+ * may be called concurrently from several host threads (kphf/mod.rs:105-109
+ * requires Self: Sync).  Streaming state lives in mz_streaming, one per thread
+ * (index/caching.rs:65 takes &mut self).
+ */
+#ifndef MAZU_AMD_H
+#define MAZU_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (reference: mazu::Error, src/err.rs:3-31; panics map to MZ_EINVAL) */
+#define MZ_OK 0
+#define MZ_EINVAL 1       /* wrong k (assert_eq!, sshash.rs:473), w > k (sshash.rs:92), k > 31, null/empty input */
+#define MZ_ENOMEM 2
+#define MZ_EHIP 3         /* no device / HIP runtime error */
+#define MZ_EIO 4          /* Error::IO / InvalidData */
+#define MZ_ENOTMONOTONE 5 /* Error::EFNotMonotone (elias_fano.rs:80-82) */
+#define MZ_EEMPTY 6       /* Error::EFEmpty (elias_fano.rs:124-131) */
+
+/* ---- MatchType (kmers crate; Orientation mapping in src/lib.rs:50-64) */
+#define MZ_NO_MATCH 0u
+#define MZ_IDENTITY_MATCH 1u
+#define MZ_TWIN_MATCH 2u
+#define MZ_SKIPPED 3u /* read window holding a non-ACGT byte: CanonicalKmerIterator skips it */
+
+#define MZ_NO_SKEW_INDEX UINT64_MAX /* from_unitig_set_no_skew_index: skew_param = usize::MAX, sshash.rs:81-84 */
+
+/* K2UPos (kphf/mod.rs:13-19) as a 16-byte record; match == MZ_NO_MATCH encodes `None`. */
+typedef struct mz_k2upos {
+    uint32_t unitig_id;
+    uint32_t pos;
+    uint32_t unitig_len;
+    uint32_t match;
+} mz_k2upos;
+
+/* hit / miss / skipped tallies, as counted by the reference bench loop (bin/kphf/main.rs:283-320) */
+typedef struct mz_counts {
+    uint64_t n_hit;
+    uint64_t n_miss;
+    uint64_t n_skipped;
+} mz_counts;
+
+/* result of a device-side validate_self (kphf/mod.rs:69-103) */
+typedef struct mz_validate_report {
+    uint64_t n_kmers;     /* k-mers visited (2 queries each) */
+    uint64_t n_fail;      /* assertions that would have fired in the reference */
+    uint64_t n_duplicate; /* mismatches explained by a duplicate canonical k-mer in the INPUT (not a cdBG) */
+    uint64_t first_fail_pos; /* global position of one failing k-mer, UINT64_MAX if none */
+} mz_validate_report;
+
+typedef struct mz_unitig_set mz_unitig_set; /* UnitigSet, unitig_set.rs:30-36 */
+typedef struct mz_sshash mz_sshash;         /* SSHash<..>, sshash.rs:39-51 (owns its UnitigSet, :44) */
+typedef struct mz_streaming mz_streaming;   /* StreamingK2U, index/caching.rs:12-17 */
+
+/* thread-local description of the last error returned on this thread */
+const char *mz_last_error(void);
+/* ABI version of this header */
+uint32_t mz_abi_version(void);
+/* number of visible HIP devices (0 when there is none; never an error) */
+int mz_device_count(void);
+
+/* ---------------------------------------------------------------- UnitigSet */
+/* UnitigSet::from_seqs(&[String], k), unitig_set.rs:74-106.  ACGT/acgt only (MZ_EINVAL otherwise). */
+int mz_unitig_set_from_seqs(const char *const *seqs, uint64_t n_seqs, uint32_t k, mz_unitig_set **out);
+/* UnitigSet::from_cf_prefix(prefix), unitig_set.rs:109-165: reads <prefix>.cf_seg and <prefix>.json */
+int mz_unitig_set_from_cf_prefix(const char *prefix, mz_unitig_set **out);
+/* same, from an already 2-bit packed concatenation: words holds ceil(total_len/32) u64,
+ * starts holds n_unitigs+1 prefix sums (the accum_lens of unitig_set.rs:80-88).  Inputs are copied. */
+int mz_unitig_set_from_packed(const uint64_t *words, uint64_t total_len, const uint64_t *starts,
+                              uint64_t n_unitigs, uint32_t k, mz_unitig_set **out);
+void mz_unitig_set_free(mz_unitig_set *us);
+uint32_t mz_unitig_set_k(const mz_unitig_set *us);                         /* :247-249 */
+uint64_t mz_unitig_set_n_unitigs(const mz_unitig_set *us);                 /* :168-170 */
+uint64_t mz_unitig_set_total_len(const mz_unitig_set *us);                 /* :207-209 */
+uint64_t mz_unitig_set_n_kmers(const mz_unitig_set *us);                   /* :212-214 */
+uint64_t mz_unitig_set_unitig_len(const mz_unitig_set *us, uint64_t i);    /* :178-180 (Elias-Fano get) */
+uint64_t mz_unitig_set_unitig_start_pos(const mz_unitig_set *us, uint64_t i); /* :196-199 */
+uint64_t mz_unitig_set_pos_to_id(const mz_unitig_set *us, uint64_t pos);   /* :185-187 */
+/* borrow of the packed sequence (valid until free): unitig i occupies bases [start,start+len) */
+const uint64_t *mz_unitig_set_useq_words(const mz_unitig_set *us);
+
+/* ------------------------------------------------------------------- SSHash */
+/* SSHash::from_unitig_set(unitigs, w, skew_param, WyHashState::with_seed(seed)), sshash.rs:405-412.
+ * skew_param == MZ_NO_SKEW_INDEX gives from_unitig_set_no_skew_index (:397-403).  The unitig set
+ * is copied (the reference takes it by value; callers clone it out of a loaded index,
+ * README.md:22).  n_threads <= 0 uses every host core. */
+int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed,
+                              int n_threads, mz_sshash **out);
+void mz_sshash_free(mz_sshash *ix);
+
+/* trait K2U accessors, kphf/mod.rs:58-67 (impl at sshash.rs:446-469) */
+uint32_t mz_sshash_k(const mz_sshash *ix);
+uint64_t mz_sshash_n_kmers(const mz_sshash *ix);
+uint64_t mz_sshash_sum_unitigs_len(const mz_sshash *ix);
+uint64_t mz_sshash_unitig_len(const mz_sshash *ix, uint64_t id);
+uint64_t mz_sshash_n_unitigs(const mz_sshash *ix);
+/* unitig_seq(id): borrow of the packed words plus the base offset/length of unitig id */
+int mz_sshash_unitig_seq(const mz_sshash *ix, uint64_t id, const uint64_t **words, uint64_t *base_offset, uint64_t *len);
+/* AsRef<UnitigSet>, sshash.rs:440-444 (borrow; do not free) */
+const mz_unitig_set *mz_sshash_as_unitig_set(const mz_sshash *ix);
+/* sshash.rs:333-339, :341-358 */
+uint32_t mz_sshash_w(const mz_sshash *ix);
+uint64_t mz_sshash_skew_param(const mz_sshash *ix);
+uint64_t mz_sshash_n_minimizers(const mz_sshash *ix);
+uint64_t mz_sshash_n_minimizer_occs(const mz_sshash *ix);
+uint64_t mz_sshash_n_kmers_in_skew_index(const mz_sshash *ix);
+uint64_t mz_sshash_num_bits(const mz_sshash *ix);
+/* bytes resident in HBM once uploaded */
+uint64_t mz_sshash_device_bytes(const mz_sshash *ix);
+
+/* place (or move) the index replica on a device; done implicitly on device 0 by the first query */
+int mz_sshash_to_device(mz_sshash *ix, int device);
+
+/* K2U::k2u(&CanonicalKmer) -> Option<K2UPos>, sshash.rs:471-554.  k must equal the index's k
+ * (the reference panics; here MZ_EINVAL).  A one-query GPU launch -- use the batch forms for speed. */
+int mz_sshash_k2u(mz_sshash *ix, uint64_t fw_word, uint32_t k, mz_k2upos *out);
+/* n independent k2u queries, host buffers (copied over PCIe); counts may be NULL */
+int mz_sshash_k2u_batch(mz_sshash *ix, const uint64_t *fw_words, uint64_t n, mz_k2upos *out, mz_counts *counts);
+/* same with queries/results/counts already in HBM on the index's device; asynchronous on `stream`
+ * (a hipStream_t; NULL = default stream).  d_counts may be NULL; otherwise it is ACCUMULATED into. */
+int mz_sshash_k2u_batch_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64_t n, mz_k2upos *d_out,
+                               mz_counts *d_counts, void *stream);
+/* hits only, compacted per wavefront: d_hit_idx[j] = query index, d_hits[j] = its K2UPos; *d_n_hits
+ * (device, zeroed by the caller) receives the count.  Order of records is unspecified. */
+int mz_sshash_k2u_batch_compact_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64_t n, uint64_t *d_hit_idx,
+                                       mz_k2upos *d_hits, uint64_t *d_n_hits, void *stream);
+
+/* reads: every k-mer window of every read, as the bench loop of bin/kphf/main.rs:299-324 walks them
+ * (CanonicalKmerIterator::from_u8_slice; windows with a non-ACGT byte are reported as MZ_SKIPPED).
+ * bases = concatenated ASCII reads, read_offsets = n_reads+1 byte offsets.  Window j of read r is
+ * written to out[kmer_offsets[r] + j] where kmer_offsets is the prefix sum of max(0, len_r - k + 1);
+ * out must hold kmer_offsets[n_reads] records (mz_reads_n_windows computes it).  `streaming` != 0
+ * requests the .as_streaming() path (index/caching.rs:65-103); results are identical by contract. */
+uint64_t mz_reads_n_windows(const uint64_t *read_offsets, uint64_t n_reads, uint32_t k);
+int mz_sshash_k2u_reads(mz_sshash *ix, const uint8_t *bases, const uint64_t *read_offsets, uint64_t n_reads,
+                        int streaming, mz_k2upos *out, mz_counts *counts);
+int mz_sshash_k2u_reads_device(mz_sshash *ix, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
+                               const uint64_t *d_kmer_offsets, uint64_t n_reads, int streaming, mz_k2upos *d_out,
+                               mz_counts *d_counts, void *stream);
+
+/* K2U::validate_self / validate_self_parallel, kphf/mod.rs:69-139, run on the device: every k-mer of
+ * every unitig is queried in both orientations and compared with (unitig, offset, len, Identity|Twin). */
+int mz_sshash_validate_self(mz_sshash *ix, mz_validate_report *report);
+
+/* forward words of the k-mers at global positions (device arrays); flip[i] != 0 returns the reverse
+ * complement instead.  Used to synthesise positive queries without leaving HBM. */
+int mz_sshash_extract_kmers_device(mz_sshash *ix, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
+                                   uint64_t *d_fw_words, void *stream);
+
+/* flat, versioned, little-endian index file (the reference bincode-serialises its structs,
+ * bin/kphf/main.rs:156,193; that format depends on un-vendored crates and is not reproduced) */
+int mz_sshash_save(const mz_sshash *ix, const char *path);
+int mz_sshash_load(const char *path, mz_sshash **out);
+
+/* ------------------------------------------------------------ StreamingK2U */
+/* SSHash::as_streaming(), sshash.rs:435-437 -> StreamingK2U::new, index/caching.rs:47-59 */
+int mz_streaming_new(mz_sshash *ix, mz_streaming **out);
+void mz_streaming_free(mz_streaming *st);
+/* StreamingK2U::k2u_streaming(&mut self, km), index/caching.rs:65-103 */
+int mz_streaming_k2u(mz_streaming *st, uint64_t fw_word, uint32_t k, mz_k2upos *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAZU_AMD_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libmazu_amd.so (the C ABI in include/mazu_amd.h).
+
+The library is mandatory: there is no Python or CPU fallback for the query path.  If the
+shared object is missing, import fails loudly with the build command to run.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmazu_amd.so")
+
+MZ_OK, MZ_EINVAL, MZ_ENOMEM, MZ_EHIP, MZ_EIO, MZ_ENOTMONOTONE, MZ_EEMPTY = range(7)
+MZ_NO_SKEW_INDEX = 2**64 - 1
+
+
+class MazuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mazu_amd error {code}: {msg}")
+        self.code = code
+
+
+class K2UPos(C.Structure):
+    _fields_ = [("unitig_id", C.c_uint32), ("pos", C.c_uint32), ("unitig_len", C.c_uint32), ("match", C.c_uint32)]
+
+
+class Counts(C.Structure):
+    _fields_ = [("n_hit", C.c_uint64), ("n_miss", C.c_uint64), ("n_skipped", C.c_uint64)]
+
+
+class ValidateReport(C.Structure):
+    _fields_ = [("n_kmers", C.c_uint64), ("n_fail", C.c_uint64), ("n_duplicate", C.c_uint64), ("first_fail_pos", C.c_uint64)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C mazu_amd/csrc`.")
+    try:  # share torch's HIP runtime when torch is present, so device pointers and streams interoperate
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    u64, u32, p, i = C.c_uint64, C.c_uint32, C.c_void_p, C.c_int
+    sig = {
+        "mz_last_error": (C.c_char_p, []),
+        "mz_abi_version": (u32, []),
+        "mz_device_count": (i, []),
+        "mz_unitig_set_from_seqs": (i, [p, u64, u32, p]),
+        "mz_unitig_set_from_cf_prefix": (i, [C.c_char_p, p]),
+        "mz_unitig_set_from_packed": (i, [p, u64, p, u64, u32, p]),
+        "mz_unitig_set_free": (None, [p]),
+        "mz_unitig_set_k": (u32, [p]),
+        "mz_unitig_set_n_unitigs": (u64, [p]),
+        "mz_unitig_set_total_len": (u64, [p]),
+        "mz_unitig_set_n_kmers": (u64, [p]),
+        "mz_unitig_set_unitig_len": (u64, [p, u64]),
+        "mz_unitig_set_unitig_start_pos": (u64, [p, u64]),
+        "mz_unitig_set_pos_to_id": (u64, [p, u64]),
+        "mz_unitig_set_useq_words": (p, [p]),
+        "mz_sshash_from_unitig_set": (i, [p, u32, u64, u64, i, p]),
+        "mz_sshash_free": (None, [p]),
+        "mz_sshash_k": (u32, [p]),
+        "mz_sshash_n_kmers": (u64, [p]),
+        "mz_sshash_sum_unitigs_len": (u64, [p]),
+        "mz_sshash_unitig_len": (u64, [p, u64]),
+        "mz_sshash_n_unitigs": (u64, [p]),
+        "mz_sshash_unitig_seq": (i, [p, u64, p, p, p]),
+        "mz_sshash_as_unitig_set": (p, [p]),
+        "mz_sshash_w": (u32, [p]),
+        "mz_sshash_skew_param": (u64, [p]),
+        "mz_sshash_n_minimizers": (u64, [p]),
+        "mz_sshash_n_minimizer_occs": (u64, [p]),
+        "mz_sshash_n_kmers_in_skew_index": (u64, [p]),
+        "mz_sshash_num_bits": (u64, [p]),
+        "mz_sshash_device_bytes": (u64, [p]),
+        "mz_sshash_to_device": (i, [p, i]),
+        "mz_sshash_k2u": (i, [p, u64, u32, p]),
+        "mz_sshash_k2u_batch": (i, [p, p, u64, p, p]),
+        "mz_sshash_k2u_batch_device": (i, [p, p, u64, p, p, p]),
+        "mz_sshash_k2u_batch_compact_device": (i, [p, p, u64, p, p, p, p]),
+        "mz_reads_n_windows": (u64, [p, u64, u32]),
+        "mz_sshash_k2u_reads": (i, [p, p, p, u64, i, p, p]),
+        "mz_sshash_k2u_reads_device": (i, [p, p, u64, p, p, u64, i, p, p, p]),
+        "mz_sshash_validate_self": (i, [p, p]),
+        "mz_sshash_extract_kmers_device": (i, [p, p, p, u64, p, p]),
+        "mz_sshash_save": (i, [p, C.c_char_p]),
+        "mz_sshash_load": (i, [C.c_char_p, p]),
+        "mz_streaming_new": (i, [p, p]),
+        "mz_streaming_free": (None, [p]),
+        "mz_streaming_k2u": (i, [p, u64, u32, p]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    L._mz_symbols = tuple(sig)
+    return L
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != MZ_OK:
+        raise MazuError(rc, (lib.mz_last_error() or b"").decode())

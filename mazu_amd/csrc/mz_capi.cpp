@@ -1,0 +1,370 @@
+// mz_capi.cpp -- the extern "C" boundary declared in include/mazu_amd.h.
+// Thin: argument checks, host<->device staging for the host-pointer entry points, and the
+// lazily created per-device replica.  All query work is done by the kernels in mz_device.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "mz_device.hpp"
+
+using namespace mz;
+
+struct mz_unitig_set {
+    UnitigSet us;
+};
+
+struct mz_sshash {
+    SSHashHost host;
+    DeviceIndex *dev = nullptr;
+    std::mutex mu;
+};
+
+struct mz_streaming {
+    mz_sshash *ix;
+    bool is_warm = false;
+    mz_k2upos prev{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, MZ_NO_MATCH};
+};
+
+#define HIPC(expr)                                                                             \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            set_error("HIP error %d (%s): %s", (int)_e, hipGetErrorString(_e), #expr);         \
+            return MZ_EHIP;                                                                    \
+        }                                                                                      \
+    } while (0)
+
+static int ensure_device(mz_sshash *ix) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->dev) return MZ_OK;
+    return device_upload(ix->host, 0, &ix->dev);
+}
+
+extern "C" {
+
+const char *mz_last_error(void) { return last_error(); }
+uint32_t mz_abi_version(void) { return 1; }
+int mz_device_count(void) { return device_count(); }
+
+// ---------------------------------------------------------------- UnitigSet
+#define NEW_US(call)                                  \
+    if (!out) { set_error("null out pointer"); return MZ_EINVAL; } \
+    *out = nullptr;                                   \
+    mz_unitig_set *u = new (std::nothrow) mz_unitig_set(); \
+    if (!u) return MZ_ENOMEM;                         \
+    int rc = u->us.call;                              \
+    if (rc != MZ_OK) { delete u; return rc; }         \
+    *out = u;                                         \
+    return MZ_OK;
+
+int mz_unitig_set_from_seqs(const char *const *seqs, uint64_t n_seqs, uint32_t k, mz_unitig_set **out) { NEW_US(from_seqs(seqs, n_seqs, k)) }
+int mz_unitig_set_from_cf_prefix(const char *prefix, mz_unitig_set **out) {
+    if (!prefix) { set_error("null prefix"); return MZ_EINVAL; }
+    NEW_US(from_cf_prefix(prefix))
+}
+int mz_unitig_set_from_packed(const uint64_t *words, uint64_t total_len, const uint64_t *starts, uint64_t n_unitigs,
+                              uint32_t k, mz_unitig_set **out) { NEW_US(from_packed(words, total_len, starts, n_unitigs, k)) }
+void mz_unitig_set_free(mz_unitig_set *us) { delete us; }
+uint32_t mz_unitig_set_k(const mz_unitig_set *us) { return us->us.k; }
+uint64_t mz_unitig_set_n_unitigs(const mz_unitig_set *us) { return us->us.n_unitigs; }
+uint64_t mz_unitig_set_total_len(const mz_unitig_set *us) { return us->us.total_len; }
+uint64_t mz_unitig_set_n_kmers(const mz_unitig_set *us) { return us->us.n_kmers(); }
+uint64_t mz_unitig_set_unitig_len(const mz_unitig_set *us, uint64_t i) { return i < us->us.n_unitigs ? us->us.unitig_len(i) : 0; }
+uint64_t mz_unitig_set_unitig_start_pos(const mz_unitig_set *us, uint64_t i) { return i <= us->us.n_unitigs ? us->us.unitig_start_pos(i) : 0; }
+uint64_t mz_unitig_set_pos_to_id(const mz_unitig_set *us, uint64_t pos) { return pos < us->us.total_len ? us->us.pos_to_id(pos) : us->us.n_unitigs; }
+const uint64_t *mz_unitig_set_useq_words(const mz_unitig_set *us) { return us->us.useq.data(); }
+
+// ------------------------------------------------------------------- SSHash
+int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int n_threads,
+                              mz_sshash **out) {
+    if (!us || !out) { set_error("null argument"); return MZ_EINVAL; }
+    *out = nullptr;
+    mz_sshash *ix = new (std::nothrow) mz_sshash();
+    if (!ix) return MZ_ENOMEM;
+    int rc;
+    try {
+        rc = ix->host.build(us->us, w, skew_param, seed, n_threads);
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory while building the index");
+        rc = MZ_ENOMEM;
+    }
+    if (rc != MZ_OK) { delete ix; return rc; }
+    *out = ix;
+    return MZ_OK;
+}
+void mz_sshash_free(mz_sshash *ix) {
+    if (!ix) return;
+    device_free(ix->dev);
+    delete ix;
+}
+uint32_t mz_sshash_k(const mz_sshash *ix) { return ix->host.us.k; }
+uint64_t mz_sshash_n_kmers(const mz_sshash *ix) { return ix->host.us.n_kmers(); }
+uint64_t mz_sshash_sum_unitigs_len(const mz_sshash *ix) { return ix->host.us.total_len; }
+uint64_t mz_sshash_unitig_len(const mz_sshash *ix, uint64_t id) { return id < ix->host.us.n_unitigs ? ix->host.us.unitig_len(id) : 0; }
+uint64_t mz_sshash_n_unitigs(const mz_sshash *ix) { return ix->host.us.n_unitigs; }
+int mz_sshash_unitig_seq(const mz_sshash *ix, uint64_t id, const uint64_t **words, uint64_t *base_offset, uint64_t *len) {
+    if (!ix || id >= ix->host.us.n_unitigs) { set_error("unitig id out of range"); return MZ_EINVAL; }
+    if (words) *words = ix->host.us.useq.data();
+    if (base_offset) *base_offset = ix->host.us.unitig_start_pos(id);
+    if (len) *len = ix->host.us.unitig_len(id);
+    return MZ_OK;
+}
+const mz_unitig_set *mz_sshash_as_unitig_set(const mz_sshash *ix) {
+    // mz_unitig_set is a struct holding exactly one UnitigSet, so the owned set can be lent in place
+    static_assert(sizeof(mz_unitig_set) == sizeof(UnitigSet), "mz_unitig_set must wrap UnitigSet only");
+    return reinterpret_cast<const mz_unitig_set *>(&ix->host.us);
+}
+uint32_t mz_sshash_w(const mz_sshash *ix) { return ix->host.w; }
+uint64_t mz_sshash_skew_param(const mz_sshash *ix) { return ix->host.skew_param; }
+uint64_t mz_sshash_n_minimizers(const mz_sshash *ix) { return ix->host.n_minimizers; }
+uint64_t mz_sshash_n_minimizer_occs(const mz_sshash *ix) { return ix->host.pos.n; }
+uint64_t mz_sshash_n_kmers_in_skew_index(const mz_sshash *ix) { return ix->host.has_skew ? ix->host.skew_pos.n : 0; }
+uint64_t mz_sshash_num_bits(const mz_sshash *ix) { return ix->host.num_bits(); }
+uint64_t mz_sshash_device_bytes(const mz_sshash *ix) { return ix->dev ? ix->dev->bytes : 0; }
+
+int mz_sshash_to_device(mz_sshash *ix, int device) {
+    if (!ix) { set_error("null index"); return MZ_EINVAL; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->dev && ix->dev->device == device) return MZ_OK;
+    DeviceIndex *nd = nullptr;
+    int rc = device_upload(ix->host, device, &nd);
+    if (rc != MZ_OK) return rc;
+    device_free(ix->dev);
+    ix->dev = nd;
+    return MZ_OK;
+}
+
+int mz_sshash_k2u_batch_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
+                               void *stream) {
+    if (!ix || (n && (!d_fw_words || !d_out))) { set_error("null argument"); return MZ_EINVAL; }
+    int rc = ensure_device(ix);
+    if (rc != MZ_OK) return rc;
+    return launch_k2u_batch(*ix->dev, d_fw_words, n, d_out, d_counts, (hipStream_t)stream);
+}
+
+int mz_sshash_k2u_batch_compact_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64_t n, uint64_t *d_hit_idx,
+                                       mz_k2upos *d_hits, uint64_t *d_n_hits, void *stream) {
+    if (!ix || !d_n_hits || (n && (!d_fw_words || !d_hit_idx || !d_hits))) { set_error("null argument"); return MZ_EINVAL; }
+    int rc = ensure_device(ix);
+    if (rc != MZ_OK) return rc;
+    return launch_k2u_compact(*ix->dev, d_fw_words, n, d_hit_idx, d_hits, d_n_hits, (hipStream_t)stream);
+}
+
+int mz_sshash_k2u_batch(mz_sshash *ix, const uint64_t *fw_words, uint64_t n, mz_k2upos *out, mz_counts *counts) {
+    if (!ix || (n && (!fw_words || !out))) { set_error("null argument"); return MZ_EINVAL; }
+    int rc = ensure_device(ix);
+    if (rc != MZ_OK) return rc;
+    if (counts) *counts = mz_counts{0, 0, 0};
+    if (n == 0) return MZ_OK;
+    HIPC(hipSetDevice(ix->dev->device));
+    uint64_t *d_q = nullptr;
+    mz_k2upos *d_o = nullptr;
+    mz_counts *d_c = nullptr;
+    hipStream_t s = nullptr;
+    HIPC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); // own stream: concurrent host threads do not serialise
+    auto cleanup = [&] { if (d_q) (void)hipFree(d_q); if (d_o) (void)hipFree(d_o); if (d_c) (void)hipFree(d_c); (void)hipStreamDestroy(s); };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_q, n * 8)) != hipSuccess || (e = hipMalloc((void **)&d_o, n * sizeof(mz_k2upos))) != hipSuccess ||
+        (e = hipMalloc((void **)&d_c, sizeof(mz_counts))) != hipSuccess) {
+        cleanup();
+        set_error("hipMalloc failed: %s", hipGetErrorString(e));
+        return MZ_ENOMEM;
+    }
+    rc = MZ_OK;
+    if ((e = hipMemcpyAsync(d_q, fw_words, n * 8, hipMemcpyHostToDevice, s)) != hipSuccess ||
+        (e = hipMemsetAsync(d_c, 0, sizeof(mz_counts), s)) != hipSuccess) rc = MZ_EHIP;
+    if (rc == MZ_OK) rc = launch_k2u_batch(*ix->dev, d_q, n, d_o, d_c, s);
+    if (rc == MZ_OK && ((e = hipMemcpyAsync(out, d_o, n * sizeof(mz_k2upos), hipMemcpyDeviceToHost, s)) != hipSuccess)) rc = MZ_EHIP;
+    mz_counts hc{0, 0, 0};
+    if (rc == MZ_OK && ((e = hipMemcpyAsync(&hc, d_c, sizeof hc, hipMemcpyDeviceToHost, s)) != hipSuccess)) rc = MZ_EHIP;
+    if (rc == MZ_OK && ((e = hipStreamSynchronize(s)) != hipSuccess)) rc = MZ_EHIP;
+    if (rc == MZ_EHIP && e != hipSuccess) set_error("HIP error in k2u_batch: %s", hipGetErrorString(e));
+    if (rc == MZ_OK && counts) *counts = hc;
+    cleanup();
+    return rc;
+}
+
+int mz_sshash_k2u(mz_sshash *ix, uint64_t fw_word, uint32_t k, mz_k2upos *out) {
+    if (!ix || !out) { set_error("null argument"); return MZ_EINVAL; }
+    if (k != ix->host.us.k) { // assert_eq!(km.k, self.k()), sshash.rs:473
+        set_error("Got query k-mer size k=%u, expected k=%u.", k, ix->host.us.k);
+        return MZ_EINVAL;
+    }
+    return mz_sshash_k2u_batch(ix, &fw_word, 1, out, nullptr);
+}
+
+uint64_t mz_reads_n_windows(const uint64_t *read_offsets, uint64_t n_reads, uint32_t k) {
+    uint64_t t = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        uint64_t len = read_offsets[r + 1] - read_offsets[r];
+        if (len >= k) t += len - k + 1;
+    }
+    return t;
+}
+
+int mz_sshash_k2u_reads_device(mz_sshash *ix, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
+                               const uint64_t *d_kmer_offsets, uint64_t n_reads, int streaming, mz_k2upos *d_out,
+                               mz_counts *d_counts, void *stream) {
+    if (!ix || (n_reads && (!d_bases || !d_read_offsets || !d_kmer_offsets || !d_out))) { set_error("null argument"); return MZ_EINVAL; }
+    int rc = ensure_device(ix);
+    if (rc != MZ_OK) return rc;
+    return launch_k2u_reads(*ix->dev, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, streaming, d_out, d_counts,
+                            (hipStream_t)stream);
+}
+
+int mz_sshash_k2u_reads(mz_sshash *ix, const uint8_t *bases, const uint64_t *read_offsets, uint64_t n_reads, int streaming,
+                        mz_k2upos *out, mz_counts *counts) {
+    if (!ix || (n_reads && (!bases || !read_offsets))) { set_error("null argument"); return MZ_EINVAL; }
+    int rc = ensure_device(ix);
+    if (rc != MZ_OK) return rc;
+    if (counts) *counts = mz_counts{0, 0, 0};
+    if (n_reads == 0) return MZ_OK;
+    const uint32_t k = ix->host.us.k;
+    std::vector<uint64_t> ko(n_reads + 1, 0);
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        if (read_offsets[r + 1] < read_offsets[r]) { set_error("read_offsets not monotone at %llu", (unsigned long long)r); return MZ_ENOTMONOTONE; }
+        uint64_t len = read_offsets[r + 1] - read_offsets[r];
+        ko[r + 1] = ko[r] + (len >= k ? len - k + 1 : 0);
+    }
+    const uint64_t base0 = read_offsets[0], n_bases = read_offsets[n_reads] - base0, n_win = ko[n_reads];
+    if (n_win && !out) { set_error("null out"); return MZ_EINVAL; }
+    std::vector<uint64_t> ro(n_reads + 1);
+    for (uint64_t r = 0; r <= n_reads; ++r) ro[r] = read_offsets[r] - base0;
+    HIPC(hipSetDevice(ix->dev->device));
+    uint8_t *d_b = nullptr;
+    uint64_t *d_ro = nullptr, *d_ko = nullptr;
+    mz_k2upos *d_o = nullptr;
+    mz_counts *d_c = nullptr;
+    hipStream_t s = nullptr;
+    HIPC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    auto cleanup = [&] {
+        if (d_b) (void)hipFree(d_b);
+        if (d_ro) (void)hipFree(d_ro);
+        if (d_ko) (void)hipFree(d_ko);
+        if (d_o) (void)hipFree(d_o);
+        if (d_c) (void)hipFree(d_c);
+        (void)hipStreamDestroy(s);
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_b, std::max<uint64_t>(n_bases, 1))) != hipSuccess ||
+        (e = hipMalloc((void **)&d_ro, (n_reads + 1) * 8)) != hipSuccess || (e = hipMalloc((void **)&d_ko, (n_reads + 1) * 8)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_o, std::max<uint64_t>(n_win, 1) * sizeof(mz_k2upos))) != hipSuccess ||
+        (e = hipMalloc((void **)&d_c, sizeof(mz_counts))) != hipSuccess) {
+        cleanup();
+        set_error("hipMalloc failed: %s", hipGetErrorString(e));
+        return MZ_ENOMEM;
+    }
+    rc = MZ_OK;
+    if ((n_bases && (e = hipMemcpyAsync(d_b, bases + base0, n_bases, hipMemcpyHostToDevice, s)) != hipSuccess) ||
+        (e = hipMemcpyAsync(d_ro, ro.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_ko, ko.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s)) != hipSuccess ||
+        (e = hipMemsetAsync(d_c, 0, sizeof(mz_counts), s)) != hipSuccess) rc = MZ_EHIP;
+    if (rc == MZ_OK) rc = launch_k2u_reads(*ix->dev, d_b, n_bases, d_ro, d_ko, n_reads, streaming, d_o, d_c, s);
+    if (rc == MZ_OK && n_win && (e = hipMemcpyAsync(out, d_o, n_win * sizeof(mz_k2upos), hipMemcpyDeviceToHost, s)) != hipSuccess) rc = MZ_EHIP;
+    mz_counts hc{0, 0, 0};
+    if (rc == MZ_OK && (e = hipMemcpyAsync(&hc, d_c, sizeof hc, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = MZ_EHIP;
+    if (rc == MZ_OK && (e = hipStreamSynchronize(s)) != hipSuccess) rc = MZ_EHIP;
+    if (rc == MZ_EHIP && e != hipSuccess) set_error("HIP error in k2u_reads: %s", hipGetErrorString(e));
+    if (rc == MZ_OK && counts) *counts = hc;
+    cleanup();
+    return rc;
+}
+
+int mz_sshash_validate_self(mz_sshash *ix, mz_validate_report *report) {
+    if (!ix || !report) { set_error("null argument"); return MZ_EINVAL; }
+    int rc = ensure_device(ix);
+    if (rc != MZ_OK) return rc;
+    HIPC(hipSetDevice(ix->dev->device));
+    uint64_t init[4] = {0, 0, 0, ~0ull}, *d_r = nullptr;
+    HIPC(hipMalloc((void **)&d_r, sizeof init));
+    hipError_t e = hipMemcpy(d_r, init, sizeof init, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = launch_validate_self(*ix->dev, d_r, nullptr);
+        if (rc == MZ_OK) e = hipMemcpy(init, d_r, sizeof init, hipMemcpyDeviceToHost); // synchronises with the null stream
+    }
+    (void)hipFree(d_r);
+    if (e != hipSuccess) { set_error("HIP error in validate_self: %s", hipGetErrorString(e)); return MZ_EHIP; }
+    if (rc != MZ_OK) return rc;
+    report->n_kmers = init[0];
+    report->n_fail = init[1];
+    report->n_duplicate = init[2];
+    report->first_fail_pos = init[3];
+    return MZ_OK;
+}
+
+int mz_sshash_extract_kmers_device(mz_sshash *ix, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
+                                   uint64_t *d_fw_words, void *stream) {
+    if (!ix || (n && (!d_positions || !d_fw_words))) { set_error("null argument"); return MZ_EINVAL; }
+    int rc = ensure_device(ix);
+    if (rc != MZ_OK) return rc;
+    return launch_extract_kmers(*ix->dev, d_positions, d_flip, n, d_fw_words, (hipStream_t)stream);
+}
+
+int mz_sshash_save(const mz_sshash *ix, const char *path) {
+    if (!ix || !path) { set_error("null argument"); return MZ_EINVAL; }
+    return ix->host.save(path);
+}
+int mz_sshash_load(const char *path, mz_sshash **out) {
+    if (!path || !out) { set_error("null argument"); return MZ_EINVAL; }
+    *out = nullptr;
+    mz_sshash *ix = new (std::nothrow) mz_sshash();
+    if (!ix) return MZ_ENOMEM;
+    int rc = ix->host.load(path);
+    if (rc != MZ_OK) { delete ix; return rc; }
+    *out = ix;
+    return MZ_OK;
+}
+
+// ------------------------------------------------------------ StreamingK2U
+int mz_streaming_new(mz_sshash *ix, mz_streaming **out) {
+    if (!ix || !out) { set_error("null argument"); return MZ_EINVAL; }
+    *out = new (std::nothrow) mz_streaming{ix};
+    return *out ? MZ_OK : MZ_ENOMEM;
+}
+void mz_streaming_free(mz_streaming *st) { delete st; }
+
+// index/caching.rs:65-103.  The warm check is the same packed-sequence comparison the reads
+// kernel performs; it is evaluated on the device as a one-position extract so that no k-mer
+// comparison is ever answered from host memory.
+int mz_streaming_k2u(mz_streaming *st, uint64_t fw_word, uint32_t k, mz_k2upos *out) {
+    if (!st || !out) { set_error("null argument"); return MZ_EINVAL; }
+    mz_sshash *ix = st->ix;
+    if (k != ix->host.us.k) { set_error("Got query k-mer size k=%u, expected k=%u.", k, ix->host.us.k); return MZ_EINVAL; }
+    int rc = ensure_device(ix);
+    if (rc != MZ_OK) return rc;
+    fw_word &= kmer_mask(k);
+    if (st->is_warm) { // k2u_warm, :73-97
+        uint64_t next_pos = (uint64_t)st->prev.pos + 1, last_km_pos = (uint64_t)st->prev.unitig_len - k;
+        if (next_pos <= last_km_pos) {
+            HIPC(hipSetDevice(ix->dev->device));
+            uint64_t gp = ix->host.us.unitig_start_pos(st->prev.unitig_id) + next_pos, kw = 0, *d = nullptr;
+            HIPC(hipMalloc((void **)&d, 16));
+            hipError_t e = hipMemcpy(d, &gp, 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                rc = launch_extract_kmers(*ix->dev, d, nullptr, 1, d + 1, nullptr);
+                if (rc == MZ_OK) e = hipMemcpy(&kw, d + 1, 8, hipMemcpyDeviceToHost);
+            }
+            (void)hipFree(d);
+            if (e != hipSuccess) { set_error("HIP error in streaming k2u: %s", hipGetErrorString(e)); return MZ_EHIP; }
+            if (rc != MZ_OK) return rc;
+            uint32_t mt = kw == fw_word ? MZ_IDENTITY_MATCH : (kw == kmer_rc(fw_word, k) ? MZ_TWIN_MATCH : MZ_NO_MATCH);
+            if (mt != MZ_NO_MATCH) {
+                st->prev.pos = (uint32_t)next_pos;
+                st->prev.match = mt;
+                *out = st->prev;
+                return MZ_OK;
+            }
+        }
+    }
+    // k2u_cold, :99-103 (`?`: a miss leaves the state untouched)
+    rc = mz_sshash_k2u_batch(ix, &fw_word, 1, out, nullptr);
+    if (rc == MZ_OK && out->match != MZ_NO_MATCH) {
+        st->prev = *out;
+        st->is_warm = true;
+    }
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,377 @@
+// mz_common.hpp -- arithmetic shared by the host builder and the gfx950 kernels.
+// Everything here is pure 64-bit integer work; the same inline functions are compiled
+// for the host (index construction) and for the device (queries) so both sides agree
+// on every hash and bit position by construction.
+#pragma once
+#include <cstdint>
+
+#include "../../include/mazu_amd.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MZ_HD __host__ __device__ __forceinline__
+#else
+#define MZ_HD inline
+#endif
+
+namespace mz {
+
+// ---- layout constants -------------------------------------------------------------
+// Rank-interleaved MPHF block (one 64-byte line):  w0 = ones before this block (over the
+// whole MPHF), w1 = six 9-bit cumulative counts (ones before data word j), w2..w7 = data.
+constexpr uint32_t kMphfDataWords = 6;
+constexpr uint32_t kMphfBitsPerBlock = 64 * kMphfDataWords; // 384
+constexpr uint32_t kMphfMaxLevels = 64;
+// Boundary block (one 64-byte line) covering 256 bases of the concatenated unitigs:
+// w0 = id of the unitig holding the block's first base, w1 = start of that unitig,
+// w2 = end (exclusive) of the unitig holding the block's last base, w3 = 0,
+// w4..w7 = bits, one per base, set at the LAST base of every unitig (unitig_set.rs:90-96).
+constexpr uint32_t kBvBasesPerBlockLog2 = 8;
+constexpr uint32_t kBvBasesPerBlock = 1u << kBvBasesPerBlockLog2;
+// Elias-Fano select sample rate: position of every 2^kEfSelLog2-th one is stored.
+constexpr uint32_t kEfSelLog2 = 4;
+
+// ---- 64x64 -> 128 multiply fold ("mum"), the wyhash primitive -----------------------
+MZ_HD uint64_t mum(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (a * b) ^ __umul64hi(a, b);
+#else
+    __uint128_t r = (__uint128_t)a * b;
+    return (uint64_t)r ^ (uint64_t)(r >> 64);
+#endif
+}
+
+constexpr uint64_t kP0 = 0xa0761d6478bd642full;
+constexpr uint64_t kP1 = 0xe7037ed1a0b428dbull;
+constexpr uint64_t kP2 = 0x8ebc6af09c88c6e3ull;
+constexpr uint64_t kP3 = 0x589965cc75374cc3ull;
+
+// Minimizer order: WyHashState(seed) applied to the w-mer word (kphf/mod.rs:32-52).  A
+// wyhash-style two-round mum of the 8-byte key; bit-compat with the wyhash crate is not
+// needed for result parity (note A) and is unpinned.
+MZ_HD uint64_t hash_mmer(uint64_t x, uint64_t seed) { return mum(mum(x ^ kP0, seed ^ kP1) ^ kP2, kP3); }
+
+// per-level MPHF hash
+MZ_HD uint64_t hash_level(uint64_t key, uint64_t level_seed) { return mum(key ^ level_seed, kP1) ^ mum(key ^ kP2, level_seed | 1); }
+
+MZ_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+// position of a key inside one MPHF level of n_blocks blocks: block chosen by the high half of
+// the hash, bit inside the block by the low half (both by multiply-shift, no division)
+MZ_HD void mphf_level_slot(uint64_t key, uint64_t level_seed, uint32_t n_blocks, uint32_t &blk, uint32_t &bit) {
+    uint64_t h = hash_level(key, level_seed);
+    blk = mulhi32((uint32_t)(h >> 32), n_blocks);
+    bit = mulhi32((uint32_t)h, kMphfBitsPerBlock);
+}
+
+// ---- 2-bit k-mer words (A=0 C=1 G=2 T=3, first base in the LSBs) ---------------------
+MZ_HD uint64_t kmer_mask(uint32_t k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1); }
+
+MZ_HD uint64_t kmer_rc(uint64_t x, uint32_t k) {
+    x = ~x;
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    lo = __builtin_bswap32(lo);
+    hi = __builtin_bswap32(hi);
+    x = ((uint64_t)lo << 32) | hi;
+#else
+    x = __builtin_bswap64(x);
+#endif
+    return x >> (64 - 2 * k);
+}
+
+// k-mer starting at base `pos` of a packed sequence (two-word read; the array is padded)
+MZ_HD uint64_t read_kmer(const uint64_t *words, uint64_t pos, uint32_t k) {
+    uint64_t b = pos * 2, wi = b >> 6;
+    uint32_t sh = (uint32_t)(b & 63);
+    uint64_t lo = words[wi], hi = words[wi + 1];
+    uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    return x & kmer_mask(k);
+}
+
+// fixed-width packed integer (IntVector::get): element i at bit i*width, array padded
+MZ_HD uint64_t read_packed(const uint64_t *words, uint64_t i, uint32_t width) {
+    uint64_t b = i * width, wi = b >> 6;
+    uint32_t sh = (uint32_t)(b & 63);
+    uint64_t lo = words[wi], hi = words[wi + 1];
+    uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    return width >= 64 ? x : (x & ((1ull << width) - 1));
+}
+
+MZ_HD uint32_t popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(x);
+#else
+    return (uint32_t)__builtin_popcountll(x);
+#endif
+}
+MZ_HD uint32_t ctz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(__ffsll((long long)x) - 1);
+#else
+    return (uint32_t)__builtin_ctzll(x);
+#endif
+}
+MZ_HD uint32_t clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__clzll((long long)x);
+#else
+    return (uint32_t)__builtin_clzll(x);
+#endif
+}
+
+// position of the r-th (0-based) set bit of x; requires r < popcount(x)
+MZ_HD uint32_t select_in_word(uint64_t x, uint32_t r) {
+    uint32_t pos = 0;
+    uint32_t lo = (uint32_t)x;
+    uint32_t c = (uint32_t)__builtin_popcount(lo);
+    if (r >= c) { r -= c; lo = (uint32_t)(x >> 32); pos = 32; }
+    c = (uint32_t)__builtin_popcount(lo & 0xFFFFu);
+    if (r >= c) { r -= c; lo >>= 16; pos += 16; }
+    c = (uint32_t)__builtin_popcount(lo & 0xFFu);
+    if (r >= c) { r -= c; lo >>= 8; pos += 8; }
+    c = (uint32_t)__builtin_popcount(lo & 0xFu);
+    if (r >= c) { r -= c; lo >>= 4; pos += 4; }
+    c = (uint32_t)__builtin_popcount(lo & 0x3u);
+    if (r >= c) { r -= c; lo >>= 2; pos += 2; }
+    if (r >= (lo & 1u)) pos += 1;
+    return pos;
+}
+
+// util.rs:48-55
+MZ_HD uint64_t msb(uint64_t n) { return n == 0 ? 0 : 63 - clz64(n); }
+MZ_HD uint32_t bit_len(uint64_t v) { return v == 0 ? 1u : 64u - clz64(v); }
+
+// Canonical minimizer of a k-mer (call site sshash.rs:476; definition sshash.rs:32-37):
+// the w-mer of g* = min(fw, rc) with the smallest hash, leftmost on ties.
+struct Minimizer {
+    uint64_t word;
+    uint32_t offset; // inside g*
+};
+MZ_HD Minimizer canonical_minimizer(uint64_t fw, uint64_t rc, uint32_t k, uint32_t w, uint64_t seed) {
+    uint64_t g = fw <= rc ? fw : rc;
+    uint64_t wmask = kmer_mask(w);
+    Minimizer best{g & wmask, 0};
+    uint64_t best_h = hash_mmer(best.word, seed);
+    for (uint32_t o = 1; o + w <= k; ++o) {
+        uint64_t m = (g >> (2 * o)) & wmask;
+        uint64_t h = hash_mmer(m, seed);
+        if (h < best_h) { best_h = h; best.word = m; best.offset = o; }
+    }
+    return best;
+}
+
+// ---- device-visible index description (plain pointers; filled by the host) -----------
+struct MphfLevel {
+    uint64_t block_off; // first block of this level
+    uint64_t seed;
+    uint32_t n_blocks;
+    uint32_t pad;
+};
+
+struct MphfView {
+    const uint64_t *blocks; // n_total_blocks * 8 words
+    const MphfLevel *levels;
+    uint32_t n_levels;
+    uint32_t pad;
+    uint64_t n_keys;
+};
+
+struct EfView {
+    const uint64_t *high; // unary high parts, padded with zero words
+    const uint64_t *sel;  // bit position of every 2^kEfSelLog2-th one
+    const uint64_t *low;  // l-bit low parts, packed
+    uint64_t n;           // number of elements
+    uint64_t n_high_words;
+    uint32_t l;
+    uint32_t pad;
+};
+
+struct IndexView {
+    uint32_t k, w;
+    uint64_t seed;
+    uint64_t total_len;
+    uint64_t n_unitigs;
+    uint64_t skew_param;
+    const uint64_t *useq;      // 2-bit packed unitig concatenation (+2 pad words)
+    const uint64_t *bv_blocks; // boundary blocks, 8 words per 256 bases
+    MphfView mm;               // minimizer -> bucket id
+    EfView buckets;            // bucket id -> [start,end) in pos  (occs_prefix_sum)
+    const uint64_t *pos;       // packed minimizer positions
+    uint32_t pos_width;
+    uint32_t has_skew;
+    MphfView skew;             // canonical k-mer -> slot in skew_pos
+    const uint64_t *skew_pos;  // packed k-mer positions
+    uint32_t skew_pos_width;
+    uint32_t pad;
+    const uint64_t *starts;    // plain unitig starts (n_unitigs+1); used by validate_self only
+};
+
+// ---- structure probes (used by both sides) -------------------------------------------
+// MPHF probe == boomphf try_hash: first level whose bit for the key is set gives the index.
+MZ_HD bool mphf_lookup(const MphfView &m, uint64_t key, uint64_t &idx) {
+    for (uint32_t lv = 0; lv < m.n_levels; ++lv) {
+        const MphfLevel L = m.levels[lv];
+        uint32_t blk, bit;
+        mphf_level_slot(key, L.seed, L.n_blocks, blk, bit);
+        const uint64_t *b = m.blocks + (L.block_off + blk) * 8;
+        uint32_t dw = bit >> 6, bi = bit & 63;
+        uint64_t word = b[2 + dw];
+        uint64_t h0 = b[0], h1 = b[1];
+        if ((word >> bi) & 1) {
+            uint64_t below = bi ? (word & ((1ull << bi) - 1)) : 0;
+            idx = h0 + ((h1 >> (9 * dw)) & 511u) + popc64(below);
+            return true;
+        }
+    }
+    return false;
+}
+
+// Elias-Fano get(i) and get(i+1) in one go (elias_fano.rs:116-122): select1 on the high bits via
+// the sampled hint, then the packed low bits.  Requires i+1 < n.
+MZ_HD void ef_get_pair(const EfView &e, uint64_t i, uint64_t &v0, uint64_t &v1) {
+    uint64_t s = e.sel[i >> kEfSelLog2];
+    uint32_t r = (uint32_t)(i & ((1u << kEfSelLog2) - 1));
+    uint64_t wi = s >> 6;
+    uint64_t word = e.high[wi] & (~0ull << (s & 63));
+    uint32_t c = popc64(word);
+    while (r >= c) {
+        r -= c;
+        ++wi;
+        word = e.high[wi];
+        c = popc64(word);
+    }
+    uint32_t b0 = select_in_word(word, r);
+    uint64_t p0 = (wi << 6) + b0;
+    // next one
+    word = b0 == 63 ? 0 : (word & (~0ull << (b0 + 1)));
+    while (word == 0) {
+        ++wi;
+        word = e.high[wi];
+    }
+    uint64_t p1 = (wi << 6) + ctz64(word);
+    uint64_t lowpair_bits = i * e.l;
+    uint64_t lw = lowpair_bits >> 6;
+    uint32_t sh = (uint32_t)(lowpair_bits & 63);
+    uint64_t a = e.low[lw], b = e.low[lw + 1];
+    uint64_t x = sh ? ((a >> sh) | (b << (64 - sh))) : a; // 64 bits from bit i*l; 2*l <= 64 asserted at build
+    uint64_t lmask = (1ull << e.l) - 1;
+    v0 = ((p0 - i) << e.l) | (x & lmask);
+    v1 = ((p1 - (i + 1)) << e.l) | ((x >> e.l) & lmask);
+}
+
+MZ_HD uint64_t ef_get(const EfView &e, uint64_t i) {
+    uint64_t s = e.sel[i >> kEfSelLog2];
+    uint32_t r = (uint32_t)(i & ((1u << kEfSelLog2) - 1));
+    uint64_t wi = s >> 6;
+    uint64_t word = e.high[wi] & (~0ull << (s & 63));
+    uint32_t c = popc64(word);
+    while (r >= c) {
+        r -= c;
+        ++wi;
+        word = e.high[wi];
+        c = popc64(word);
+    }
+    uint64_t p0 = (wi << 6) + select_in_word(word, r);
+    return ((p0 - i) << e.l) | read_packed(e.low, i, e.l);
+}
+
+// Boundary block probe: unitig id, start and end of the unitig that holds global base `pos`
+// (== bv.rank(pos) + accum_lens.get(id) + accum_lens.get(id+1), unitig_set.rs:178-204) from ONE line.
+struct UnitigSpan {
+    uint64_t id, start, end;
+};
+MZ_HD UnitigSpan locate_unitig(const uint64_t *bv_blocks, uint64_t pos) {
+    const uint64_t *b = bv_blocks + (pos >> kBvBasesPerBlockLog2) * 8;
+    uint32_t off = (uint32_t)(pos & (kBvBasesPerBlock - 1));
+    uint64_t base = pos & ~(uint64_t)(kBvBasesPerBlock - 1);
+    uint64_t id0 = b[0], start0 = b[1], end_last = b[2];
+    uint64_t d[4] = {b[4], b[5], b[6], b[7]};
+    uint32_t wsel = off >> 6, bi = off & 63;
+    uint64_t below_mask = bi ? ((1ull << bi) - 1) : 0;
+    UnitigSpan s;
+    uint32_t rank = 0;
+    int last_below = -1;  // highest set bit strictly below off
+    int first_at = -1;    // lowest set bit at or above off
+    for (uint32_t j = 0; j < 4; ++j) {
+        uint64_t w = d[j];
+        uint64_t lo = j < wsel ? w : (j == wsel ? (w & below_mask) : 0);
+        uint64_t hi = j > wsel ? w : (j == wsel ? (w & ~below_mask) : 0);
+        rank += popc64(lo);
+        if (lo) last_below = (int)(j * 64 + 63 - clz64(lo));
+        if (hi && first_at < 0) first_at = (int)(j * 64 + ctz64(hi));
+    }
+    s.id = id0 + rank;
+    s.start = last_below >= 0 ? base + (uint64_t)last_below + 1 : start0;
+    s.end = first_at >= 0 ? base + (uint64_t)first_at + 1 : end_last;
+    return s;
+}
+
+// ---- the k2u lookup chain (reference src/kphf/sshash.rs:471-554) ------------------------
+// Compiled for the device by mz_device.hip (the product path).  tests/cpp/host_check.cpp also
+// compiles it for the host to debug the builder without a GPU; libmazu_amd.so exports no host
+// query entry point.
+MZ_HD mz_k2upos make_none() { return mz_k2upos{0u, 0u, 0u, MZ_NO_MATCH}; }
+
+// CanonicalKmer::get_word_equivalency (sshash.rs:503,532): Identity is tested first
+MZ_HD uint32_t word_equivalency(uint64_t fw, uint64_t rc, uint64_t kw) {
+    return kw == fw ? MZ_IDENTITY_MATCH : (kw == rc ? MZ_TWIN_MATCH : MZ_NO_MATCH);
+}
+
+MZ_HD mz_k2upos make_hit(const UnitigSpan &s, uint64_t km_pos, uint32_t mt) {
+    return mz_k2upos{(uint32_t)s.id, (uint32_t)(km_pos - s.start), (uint32_t)(s.end - s.start), mt};
+}
+
+// sshash.rs:415-433 + SkewIndex::lookup :59-66
+MZ_HD mz_k2upos skew_lookup(const IndexView &ix, uint64_t fw, uint64_t rc) {
+    if (!ix.has_skew) return make_none();
+    uint64_t word = fw < rc ? fw : rc, h;
+    if (!mphf_lookup(ix.skew, word, h)) return make_none();
+    uint64_t p = read_packed(ix.skew_pos, h, ix.skew_pos_width);
+    uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, ix.k));
+    if (mt == MZ_NO_MATCH) return make_none();
+    return make_hit(locate_unitig(ix.bv_blocks, p), p, mt);
+}
+
+// sshash.rs:478-554 once the canonical minimizer is known
+MZ_HD mz_k2upos lookup_with_minimizer(const IndexView &ix, uint64_t fw, uint64_t rc, Minimizer mn) {
+    const uint32_t k = ix.k, w = ix.w;
+    uint64_t h;
+    if (!mphf_lookup(ix.mm, mn.word, h)) return make_none();       // :478-479
+    uint64_t ps, pe;
+    ef_get_pair(ix.buckets, h, ps, pe);                            // :482-483
+    if (pe - ps > ix.skew_param) return skew_lookup(ix, fw, rc);   // :486-490
+    const uint64_t last_km_start = ix.total_len - k;               // :492
+    const uint64_t off_a = mn.offset, off_b = k - mn.offset - w;   // :493
+    for (uint64_t pi = ps; pi < pe; ++pi) {                        // :494
+        uint64_t mm_pos = read_packed(ix.pos, pi, ix.pos_width);
+        bool va = mm_pos >= off_a && mm_pos - off_a <= last_km_start; // :498
+        bool vb = mm_pos >= off_b && mm_pos - off_b <= last_km_start; // :527
+        uint64_t pa = mm_pos - off_a, pb = mm_pos - off_b;
+        // both candidate reads are issued before either is consumed
+        uint64_t ka = va ? read_kmer(ix.useq, pa, k) : 0, kb = vb ? read_kmer(ix.useq, pb, k) : 0;
+        uint32_t ma = va ? word_equivalency(fw, rc, ka) : MZ_NO_MATCH;
+        uint32_t mb = vb ? word_equivalency(fw, rc, kb) : MZ_NO_MATCH;
+        if (ma != MZ_NO_MATCH) {
+            UnitigSpan s = locate_unitig(ix.bv_blocks, pa);
+            if (pa + k <= s.end) return make_hit(s, pa, ma);       // :509-514
+        }
+        if (mb != MZ_NO_MATCH) {
+            UnitigSpan s = locate_unitig(ix.bv_blocks, pb);
+            if (pb + k <= s.end) return make_hit(s, pb, mb);       // :538-541
+        }
+    }
+    return make_none();                                            // :553
+}
+
+MZ_HD mz_k2upos lookup(const IndexView &ix, uint64_t fw) {
+    fw &= kmer_mask(ix.k);
+    uint64_t rc = kmer_rc(fw, ix.k);
+    Minimizer mn = canonical_minimizer(fw, rc, ix.k, ix.w, ix.seed); // :476
+    return lookup_with_minimizer(ix, fw, rc, mn);
+}
+
+
+} // namespace mz

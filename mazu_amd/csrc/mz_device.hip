@@ -1,0 +1,399 @@
+// mz_device.hip -- gfx950 (MI355X / CDNA4) kernels for the SSHash k-mer -> unitig path.
+//
+// Every kernel is pure 64-bit integer work on a latency/bandwidth-bound gather chain
+// (no MFMA): one query per lane, 64-lane wavefronts, results written as coalesced 16-byte
+// records, hit tallies reduced with wavefront ballots so each wave issues one atomic.
+// Reference for the algorithm: src/kphf/sshash.rs:471-554 (k2u), :415-433 (skew),
+// src/index/caching.rs:65-103 (streaming), src/kphf/mod.rs:69-139 (validate_self).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "mz_device.hpp"
+
+namespace mz {
+
+#define MZ_HIP_CHECK(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            set_error("HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+            return MZ_EHIP;                                                                 \
+        }                                                                                   \
+    } while (0)
+
+constexpr int kBlock = 256;
+
+// one atomic per wavefront: lanes ballot, the first active lane adds the popcounts
+__device__ __forceinline__ void wave_tally(mz_counts *counts, bool hit, bool miss, bool skipped) {
+    unsigned long long bh = __ballot(hit), bm = __ballot(miss), bs = __ballot(skipped);
+    unsigned long long active = __ballot(1);
+    if (counts && (__lane_id() == (unsigned)(__ffsll((long long)active) - 1))) {
+        if (bh) atomicAdd((unsigned long long *)&counts->n_hit, (unsigned long long)__popcll(bh));
+        if (bm) atomicAdd((unsigned long long *)&counts->n_miss, (unsigned long long)__popcll(bm));
+        if (bs) atomicAdd((unsigned long long *)&counts->n_skipped, (unsigned long long)__popcll(bs));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K: batched point queries (mz_sshash_k2u_batch_device)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k2u_batch_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
+                                                           mz_k2upos *__restrict__ out, mz_counts *counts) {
+    uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        mz_k2upos r = lookup(ix, fw_words[i]);
+        out[i] = r;
+        wave_tally(counts, r.match != MZ_NO_MATCH, r.match == MZ_NO_MATCH, false);
+    }
+}
+
+// hits only, compacted per wavefront with a ballot + prefix popcount (K7)
+__global__ __launch_bounds__(kBlock) void k2u_compact_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
+                                                             uint64_t *__restrict__ hit_idx, mz_k2upos *__restrict__ hits,
+                                                             unsigned long long *n_hits) {
+    uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        mz_k2upos r = lookup(ix, fw_words[i]);
+        bool hit = r.match != MZ_NO_MATCH;
+        unsigned long long b = __ballot(hit);
+        unsigned long long active = __ballot(1);
+        unsigned lane = __lane_id();
+        unsigned leader = (unsigned)(__ffsll((long long)active) - 1);
+        unsigned long long base = 0;
+        if (lane == leader && b) base = atomicAdd(n_hits, (unsigned long long)__popcll(b));
+        base = __shfl(base, (int)leader);
+        if (hit) {
+            unsigned long long slot = base + __popcll(b & ((1ull << lane) - 1));
+            hit_idx[slot] = i;
+            hits[slot] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K: reads (mz_sshash_k2u_reads_device).  One workgroup = 256 consecutive base positions of
+// the concatenated read buffer.  The window is staged in LDS as three bit planes (low code
+// bit, high code bit, invalid) built with wavefront ballots; every w-mer hash of the tile is
+// computed ONCE into LDS (forward and reverse-complement strand) and each lane takes the
+// minimum over its k-w+1 window instead of re-hashing -- the sliding-window minimizer.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t spread_bits(uint32_t x) {
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+__device__ __forceinline__ uint32_t plane_window(const uint64_t *plane, uint32_t t, uint32_t nbits) {
+    uint32_t wi = t >> 6, sh = t & 63;
+    uint64_t x = plane[wi] >> sh;
+    if (sh) x |= plane[wi + 1] << (64 - sh);
+    return (uint32_t)(x & ((1ull << nbits) - 1));
+}
+__device__ __forceinline__ uint32_t base_code_dev(uint8_t c) {
+    c &= 0xDF; // fold case
+    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+
+constexpr int kTile = kBlock;           // base positions per workgroup
+constexpr int kTileWords = kTile / 64 + 2; // plane words incl. tail + pad
+
+__global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
+                                                           const uint64_t *__restrict__ read_offsets,
+                                                           const uint64_t *__restrict__ kmer_offsets, uint64_t n_reads,
+                                                           mz_k2upos *__restrict__ out, mz_counts *counts) {
+    __shared__ uint64_t plane_lo[kTileWords], plane_hi[kTileWords], plane_inv[kTileWords];
+    __shared__ uint64_t hf[kTile + 32], hr[kTile + 32];
+    __shared__ uint64_t s_read0;
+    const uint32_t k = ix.k, w = ix.w, n_win = k - w + 1;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint64_t B0 = (uint64_t)blockIdx.x * kTile;
+
+    if (t < kTileWords) { plane_lo[t] = 0; plane_hi[t] = 0; plane_inv[t] = 0; }
+    if (t == 0) { // read holding the first base of the tile: largest r with read_offsets[r] <= B0
+        uint64_t lo = 0, hi = n_reads; // invariant: read_offsets[lo] <= B0 (read_offsets[0] == 0)
+        while (hi - lo > 1) {
+            uint64_t mid = (lo + hi) >> 1;
+            if (read_offsets[mid] <= B0) lo = mid; else hi = mid;
+        }
+        s_read0 = lo;
+    }
+    __syncthreads();
+    // stage: main 256 positions (one ballot triple per wave) then the k-1 tail (wave 0)
+    {
+        uint64_t b = B0 + t;
+        uint32_t c = b < n_bases ? base_code_dev(bases[b]) : 4u;
+        unsigned long long blo = __ballot(c & 1u), bhi = __ballot((c >> 1) & 1u), binv = __ballot(c >> 2);
+        if (lane == 0) { plane_lo[wave] = blo; plane_hi[wave] = bhi; plane_inv[wave] = binv; }
+        if (wave == 0) {
+            uint64_t bt = B0 + kTile + lane;
+            uint32_t ct = (lane < k - 1 && bt < n_bases) ? base_code_dev(bases[bt]) : 4u;
+            unsigned long long tlo = __ballot(ct & 1u), thi = __ballot((ct >> 1) & 1u), tinv = __ballot(ct >> 2);
+            if (lane == 0) { plane_lo[kTile / 64] = tlo; plane_hi[kTile / 64] = thi; plane_inv[kTile / 64] = tinv; }
+        }
+    }
+    __syncthreads();
+    // w-mer hashes of the tile, both strands (positions t and, for the first k-w lanes, kTile+t)
+    for (uint32_t j = t; j < kTile + n_win - 1; j += kBlock) {
+        uint64_t m = spread_bits(plane_window(plane_lo, j, w)) | (spread_bits(plane_window(plane_hi, j, w)) << 1);
+        hf[j] = hash_mmer(m, ix.seed);
+        hr[j] = hash_mmer(kmer_rc(m, w), ix.seed);
+    }
+    __syncthreads();
+
+    const uint64_t b = B0 + t;
+    bool has_window = false, valid = false;
+    uint64_t out_idx = 0;
+    if (b < n_bases) {
+        uint64_t r = s_read0;
+        while (r + 1 < n_reads && read_offsets[r + 1] <= b) ++r;
+        uint64_t rs = read_offsets[r], re = read_offsets[r + 1];
+        if (b >= rs && b + k <= re) {
+            has_window = true;
+            out_idx = kmer_offsets[r] + (b - rs);
+            valid = plane_window(plane_inv, t, k) == 0;
+        }
+    }
+    mz_k2upos res = make_none();
+    if (has_window) {
+        if (valid) {
+            uint64_t fw = spread_bits(plane_window(plane_lo, t, k)) | (spread_bits(plane_window(plane_hi, t, k)) << 1);
+            uint64_t rc = kmer_rc(fw, k);
+            Minimizer mn;
+            if (fw <= rc) { // g* = fw: leftmost minimum of the forward hashes
+                uint32_t bo = 0;
+                uint64_t bh = hf[t];
+                for (uint32_t o = 1; o < n_win; ++o) {
+                    uint64_t h = hf[t + o];
+                    if (h < bh) { bh = h; bo = o; }
+                }
+                mn.offset = bo;
+                mn.word = (fw >> (2 * bo)) & kmer_mask(w);
+            } else { // g* = rc: offset o of g* is forward position t + (k-w-o); leftmost o == rightmost j
+                uint32_t bj = 0;
+                uint64_t bh = hr[t];
+                for (uint32_t j = 1; j < n_win; ++j) {
+                    uint64_t h = hr[t + j];
+                    if (h <= bh) { bh = h; bj = j; }
+                }
+                mn.offset = (k - w) - bj;
+                mn.word = (rc >> (2 * mn.offset)) & kmer_mask(w);
+            }
+            res = lookup_with_minimizer(ix, fw, rc, mn);
+        } else {
+            res.match = MZ_SKIPPED;
+        }
+        out[out_idx] = res;
+    }
+    wave_tally(counts, has_window && valid && res.match != MZ_NO_MATCH, has_window && valid && res.match == MZ_NO_MATCH,
+               has_window && !valid);
+}
+
+// ------------------------------------------------------------------------------------
+// K: validate_self on the device (kphf/mod.rs:69-139): thread per global base position
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, unsigned long long *report) {
+    __shared__ uint64_t s_uid0;
+    const uint32_t k = ix.k;
+    const uint64_t P0 = (uint64_t)blockIdx.x * kBlock;
+    if (threadIdx.x == 0) {
+        uint64_t lo = 0, hi = ix.n_unitigs;
+        while (hi - lo > 1) {
+            uint64_t mid = (lo + hi) >> 1;
+            if (ix.starts[mid] <= P0) lo = mid; else hi = mid;
+        }
+        s_uid0 = lo;
+    }
+    __syncthreads();
+    const uint64_t p = P0 + threadIdx.x;
+    unsigned n_k = 0, n_fail = 0, n_dup = 0;
+    if (p + k <= ix.total_len) {
+        uint64_t ui = s_uid0;
+        while (ix.starts[ui + 1] <= p) ++ui;
+        uint64_t us = ix.starts[ui], ue = ix.starts[ui + 1];
+        if (p + k <= ue) {
+            n_k = 1;
+            uint64_t fw = read_kmer(ix.useq, p, k), rc = kmer_rc(fw, k);
+            for (int o = 0; o < 2; ++o) { // km, then km.swap()
+                uint64_t q = o ? rc : fw;
+                mz_k2upos r = lookup(ix, q);
+                uint32_t want = o ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH;
+                bool ok = r.match == want && r.unitig_id == (uint32_t)ui && r.pos == (uint32_t)(p - us) &&
+                          r.unitig_len == (uint32_t)(ue - us);
+                if (!ok) {
+                    bool dup = false;
+                    if (r.match != MZ_NO_MATCH && r.unitig_id < ix.n_unitigs) {
+                        uint64_t at = ix.starts[r.unitig_id] + r.pos;
+                        if (at + k <= ix.total_len) {
+                            uint64_t kw = read_kmer(ix.useq, at, k);
+                            dup = (kw == fw || kw == rc) && at != p;
+                        }
+                    }
+                    if (dup) ++n_dup; else { ++n_fail; atomicMin(&report[3], (unsigned long long)p); }
+                }
+            }
+        }
+    }
+    // wave reduce with ballots over the three small counters
+    for (int off = 32; off > 0; off >>= 1) {
+        n_k += __shfl_down(n_k, off);
+        n_fail += __shfl_down(n_fail, off);
+        n_dup += __shfl_down(n_dup, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_k) atomicAdd(&report[0], (unsigned long long)n_k);
+        if (n_fail) atomicAdd(&report[1], (unsigned long long)n_fail);
+        if (n_dup) atomicAdd(&report[2], (unsigned long long)n_dup);
+    }
+}
+
+// forward words at given global positions (positive-query synthesis, stays in HBM)
+__global__ __launch_bounds__(kBlock) void extract_kmers_kernel(IndexView ix, const uint64_t *__restrict__ positions,
+                                                               const uint8_t *__restrict__ flip, uint64_t n,
+                                                               uint64_t *__restrict__ fw_words) {
+    uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint64_t p = positions[i];
+        uint64_t x = p + ix.k <= ix.total_len ? read_kmer(ix.useq, p, ix.k) : 0;
+        fw_words[i] = (flip && flip[i]) ? kmer_rc(x, ix.k) : x;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side: device replica + launchers
+// ------------------------------------------------------------------------------------
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+template <class T>
+static int upload(DeviceIndex *d, const T *src, uint64_t count, const T **dst) {
+    uint64_t bytes = std::max<uint64_t>(count, 1) * sizeof(T);
+    void *p = nullptr;
+    MZ_HIP_CHECK(hipMalloc(&p, bytes));
+    d->allocs.push_back(p);
+    d->bytes += bytes;
+    if (count) MZ_HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T *)p;
+    return MZ_OK;
+}
+
+static int upload_mphf(DeviceIndex *d, const Mphf &m, MphfView *v) {
+    int rc;
+    *v = m.view();
+    if ((rc = upload(d, m.blocks.data(), m.blocks.size(), &v->blocks)) != MZ_OK) return rc;
+    if ((rc = upload(d, m.levels.data(), m.levels.size(), &v->levels)) != MZ_OK) return rc;
+    return MZ_OK;
+}
+
+int device_upload(const SSHashHost &h, int device, DeviceIndex **out) {
+    int n = device_count();
+    if (n <= 0) {
+        set_error("no HIP device visible: the k2u path runs on the GPU only (no CPU fallback)");
+        return MZ_EHIP;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (have %d)", device, n);
+        return MZ_EINVAL;
+    }
+    MZ_HIP_CHECK(hipSetDevice(device));
+    DeviceIndex *d = new DeviceIndex();
+    d->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) d->n_cu = (uint32_t)prop.multiProcessorCount;
+    IndexView v = h.view();
+    int rc = MZ_OK;
+    auto fail = [&](int code) { device_free(d); return code; };
+    if ((rc = upload(d, h.us.useq.data(), h.us.useq.size(), &v.useq)) != MZ_OK) return fail(rc);
+    if ((rc = upload(d, h.us.bv_blocks.data(), h.us.bv_blocks.size(), &v.bv_blocks)) != MZ_OK) return fail(rc);
+    if ((rc = upload(d, h.us.starts.data(), h.us.starts.size(), &v.starts)) != MZ_OK) return fail(rc);
+    if ((rc = upload_mphf(d, h.mm, &v.mm)) != MZ_OK) return fail(rc);
+    if ((rc = upload(d, h.buckets.high.data(), h.buckets.high.size(), &v.buckets.high)) != MZ_OK) return fail(rc);
+    if ((rc = upload(d, h.buckets.sel.data(), h.buckets.sel.size(), &v.buckets.sel)) != MZ_OK) return fail(rc);
+    if ((rc = upload(d, h.buckets.low.data(), h.buckets.low.size(), &v.buckets.low)) != MZ_OK) return fail(rc);
+    if ((rc = upload(d, h.pos.w.data(), h.pos.w.size(), &v.pos)) != MZ_OK) return fail(rc);
+    if (h.has_skew) {
+        if ((rc = upload_mphf(d, h.skew, &v.skew)) != MZ_OK) return fail(rc);
+        if ((rc = upload(d, h.skew_pos.w.data(), h.skew_pos.w.size(), &v.skew_pos)) != MZ_OK) return fail(rc);
+    }
+    d->view = v;
+    *out = d;
+    return MZ_OK;
+}
+
+void device_free(DeviceIndex *d) {
+    if (!d) return;
+    if (d->device >= 0) (void)hipSetDevice(d->device);
+    for (void *p : d->allocs) (void)hipFree(p);
+    delete d;
+}
+
+static unsigned grid_for(const DeviceIndex &d, uint64_t n_items, unsigned blocks_per_cu) {
+    uint64_t need = (n_items + kBlock - 1) / kBlock;
+    uint64_t cap = (uint64_t)d.n_cu * blocks_per_cu;
+    return (unsigned)std::max<uint64_t>(1, std::min(need, cap));
+}
+
+int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
+                     hipStream_t stream) {
+    if (n == 0) return MZ_OK;
+    MZ_HIP_CHECK(hipSetDevice(d.device));
+    hipLaunchKernelGGL(k2u_batch_kernel, dim3(grid_for(d, n, 32)), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
+    MZ_HIP_CHECK(hipGetLastError());
+    return MZ_OK;
+}
+
+int launch_k2u_compact(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, uint64_t *d_hit_idx, mz_k2upos *d_hits,
+                       uint64_t *d_n_hits, hipStream_t stream) {
+    if (n == 0) return MZ_OK;
+    MZ_HIP_CHECK(hipSetDevice(d.device));
+    hipLaunchKernelGGL(k2u_compact_kernel, dim3(grid_for(d, n, 32)), dim3(kBlock), 0, stream, d.view, d_fw, n, d_hit_idx, d_hits,
+                       (unsigned long long *)d_n_hits);
+    MZ_HIP_CHECK(hipGetLastError());
+    return MZ_OK;
+}
+
+int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
+                     const uint64_t *d_kmer_offsets, uint64_t n_reads, int /*streaming*/, mz_k2upos *d_out,
+                     mz_counts *d_counts, hipStream_t stream) {
+    if (n_bases == 0 || n_reads == 0) return MZ_OK;
+    MZ_HIP_CHECK(hipSetDevice(d.device));
+    uint64_t n_tiles = (n_bases + kTile - 1) / kTile;
+    if (n_tiles > 0x7FFFFFFFull) {
+        set_error("reads batch too large (%llu bases)", (unsigned long long)n_bases);
+        return MZ_EINVAL;
+    }
+    hipLaunchKernelGGL(k2u_reads_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, stream, d.view, d_bases, n_bases,
+                       d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
+    MZ_HIP_CHECK(hipGetLastError());
+    return MZ_OK;
+}
+
+int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, hipStream_t stream) {
+    MZ_HIP_CHECK(hipSetDevice(d.device));
+    uint64_t n_blocks = (d.view.total_len + kBlock - 1) / kBlock;
+    if (n_blocks > 0x7FFFFFFFull) {
+        set_error("validate_self: sequence too long for one launch");
+        return MZ_EINVAL;
+    }
+    hipLaunchKernelGGL(validate_self_kernel, dim3((unsigned)n_blocks), dim3(kBlock), 0, stream, d.view,
+                       (unsigned long long *)d_report);
+    MZ_HIP_CHECK(hipGetLastError());
+    return MZ_OK;
+}
+
+int launch_extract_kmers(const DeviceIndex &d, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
+                         uint64_t *d_fw, hipStream_t stream) {
+    if (n == 0) return MZ_OK;
+    MZ_HIP_CHECK(hipSetDevice(d.device));
+    hipLaunchKernelGGL(extract_kmers_kernel, dim3(grid_for(d, n, 32)), dim3(kBlock), 0, stream, d.view, d_positions, d_flip, n, d_fw);
+    MZ_HIP_CHECK(hipGetLastError());
+    return MZ_OK;
+}
+
+} // namespace mz

@@ -1,0 +1,39 @@
+// mz_device.hpp -- device replica of an SSHash index and the kernel launchers (gfx950).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/mazu_amd.h"
+#include "mz_host.hpp"
+
+namespace mz {
+
+struct DeviceIndex {
+    int device = -1;
+    IndexView view{};          // device pointers
+    std::vector<void *> allocs; // everything hipMalloc'ed for this replica
+    uint64_t bytes = 0;
+    uint32_t n_cu = 256;
+};
+
+int device_count();
+// copies every array of `h` into HBM of `device`
+int device_upload(const SSHashHost &h, int device, DeviceIndex **out);
+void device_free(DeviceIndex *d);
+
+// all launchers are asynchronous on `stream`; pointers are device pointers on d.device
+int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
+                     hipStream_t stream);
+int launch_k2u_compact(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, uint64_t *d_hit_idx, mz_k2upos *d_hits,
+                       uint64_t *d_n_hits, hipStream_t stream);
+int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
+                     const uint64_t *d_kmer_offsets, uint64_t n_reads, int streaming, mz_k2upos *d_out,
+                     mz_counts *d_counts, hipStream_t stream);
+// d_report: 4 x u64 {n_kmers, n_fail, n_duplicate, first_fail_pos}; caller initialises {0,0,0,~0}
+int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, hipStream_t stream);
+int launch_extract_kmers(const DeviceIndex &d, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
+                         uint64_t *d_fw, hipStream_t stream);
+
+} // namespace mz

@@ -1,0 +1,727 @@
+// mz_host.cpp -- index construction on the host (multi-threaded C++17).
+// Steps mirror reference src/kphf/sshash.rs:86-329; the produced arrays are the HBM layout
+// described in DESIGN.md.  No query code lives here: queries run on the GPU only.
+#include "mz_host.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <thread>
+
+#include "../../include/mazu_amd.h"
+
+namespace mz {
+
+// ------------------------------------------------------------------ errors / threads
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *last_error() { return g_err; }
+
+int hw_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    return n ? (int)n : 1;
+}
+
+// run fn(tid, begin, end) over [0, n) split into contiguous shards
+template <class F>
+static void parallel_for(int n_threads, uint64_t n, F fn) {
+    if (n_threads <= 1 || n < 4096) {
+        fn(0, (uint64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    uint64_t per = (n + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        uint64_t b = std::min<uint64_t>(n, per * t), e = std::min<uint64_t>(n, b + per);
+        if (b >= e) break;
+        th.emplace_back([=] { fn(t, b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+
+// run fn(tid, task) for task in [0, n_tasks) with dynamic scheduling
+template <class F>
+static void parallel_tasks(int n_threads, uint64_t n_tasks, F fn) {
+    if (n_threads <= 1 || n_tasks <= 1) {
+        for (uint64_t i = 0; i < n_tasks; ++i) fn(0, i);
+        return;
+    }
+    std::atomic<uint64_t> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t] {
+            for (;;) {
+                uint64_t i = next.fetch_add(1);
+                if (i >= n_tasks) break;
+                fn(t, i);
+            }
+        });
+    for (auto &x : th) x.join();
+}
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------ PackedVec
+void PackedVec::assign(const uint64_t *xs, uint64_t n_, uint64_t max_value, int n_threads) {
+    n = n_;
+    width = bit_len(max_value);
+    uint64_t n_words = (n * width + 63) / 64 + 2;
+    w.assign(n_words, 0);
+    // shard on word-aligned element boundaries so no two threads touch one word:
+    // element e starts a new word when e*width % 64 == 0, i.e. e multiple of 64/gcd(width,64) <= 64
+    uint64_t n_groups = (n + 63) / 64;
+    uint64_t *W = w.data();
+    uint32_t wd = width;
+    parallel_for(n_threads, n_groups, [=](int, uint64_t gb, uint64_t ge) {
+        uint64_t eb = gb * 64, ee = std::min(n, ge * 64);
+        uint64_t mask = wd >= 64 ? ~0ull : ((1ull << wd) - 1);
+        for (uint64_t i = eb; i < ee; ++i) {
+            uint64_t b = i * wd, wi = b >> 6;
+            uint32_t sh = (uint32_t)(b & 63);
+            uint64_t x = xs[i] & mask;
+            W[wi] |= x << sh;
+            if (sh + wd > 64) W[wi + 1] |= x >> (64 - sh);
+        }
+    });
+}
+
+// ------------------------------------------------------------------ Elias-Fano
+// reference src/elias_fano.rs:55-114 (from_iter)
+int EFVector::build(const uint64_t *xs, uint64_t n_, uint64_t u_) {
+    if (n_ == 0) {
+        set_error("Elias-Fano: empty sequence (Error::EFEmpty)");
+        return MZ_EEMPTY;
+    }
+    n = n_;
+    u = u_;
+    uint64_t lb = msb(u / n);
+    if (lb == 0) lb = 1; // "hack to avoid l == 0", elias_fano.rs:65-75
+    l = (uint32_t)lb;
+    if (l > 32) {
+        set_error("Elias-Fano: low width %u > 32 unsupported", l);
+        return MZ_EINVAL;
+    }
+    n_high_bits = n + (u >> l);
+    high.assign(n_high_bits / 64 + 4, 0);
+    low.assign((n * l + 63) / 64 + 2, 0);
+    uint64_t low_mask = (1ull << l) - 1, last = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t x = xs[i];
+        if (x < last) {
+            set_error("Elias-Fano: sequence not monotone at %llu (Error::EFNotMonotone)", (unsigned long long)i);
+            return MZ_ENOTMONOTONE;
+        }
+        last = x;
+        uint64_t hb = (x >> l) + i; // == h0s + i + gap of the reference loop
+        high[hb >> 6] |= 1ull << (hb & 63);
+        uint64_t b = i * l, wi = b >> 6;
+        uint32_t sh = (uint32_t)(b & 63);
+        uint64_t lo = x & low_mask;
+        low[wi] |= lo << sh;
+        if (sh + l > 64) low[wi + 1] |= lo >> (64 - sh);
+    }
+    // select samples: bit position of one number j*2^kEfSelLog2
+    sel.assign((n >> kEfSelLog2) + 2, 0);
+    uint64_t ones = 0;
+    for (uint64_t wi = 0; wi < high.size(); ++wi) {
+        uint64_t word = high[wi];
+        while (word) {
+            if ((ones & ((1u << kEfSelLog2) - 1)) == 0) sel[ones >> kEfSelLog2] = (wi << 6) + ctz64(word);
+            ++ones;
+            word &= word - 1;
+        }
+    }
+    return MZ_OK;
+}
+
+// ------------------------------------------------------------------ MPHF
+int Mphf::build(const uint64_t *keys_in, uint64_t n, double gamma, int n_threads) {
+    n_keys = n;
+    blocks.clear();
+    levels.clear();
+    std::vector<uint64_t> keys(keys_in, keys_in + n), next_keys;
+    std::vector<uint64_t> occ, col;
+    uint64_t total_blocks = 0;
+    uint64_t lvl_seed = 0x9E3779B97F4A7C15ull;
+    while (!keys.empty()) {
+        if (levels.size() >= kMphfMaxLevels) {
+            set_error("MPHF: more than %u levels (duplicate keys?)", kMphfMaxLevels);
+            return MZ_EINVAL;
+        }
+        uint64_t rem = keys.size();
+        uint64_t nb = (uint64_t)((gamma * (double)rem) / kMphfBitsPerBlock) + 1;
+        if (nb > 0xFFFFFFFFull) {
+            set_error("MPHF: level too large");
+            return MZ_EINVAL;
+        }
+        lvl_seed = lvl_seed * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull;
+        MphfLevel L{total_blocks, lvl_seed, (uint32_t)nb, 0};
+        occ.assign(nb * kMphfDataWords, 0);
+        col.assign(nb * kMphfDataWords, 0);
+        uint64_t *O = occ.data(), *Cc = col.data();
+        const uint64_t *K = keys.data();
+        parallel_for(n_threads, rem, [=](int, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+                uint32_t blk, bit;
+                mphf_level_slot(K[i], L.seed, L.n_blocks, blk, bit);
+                uint64_t wi = (uint64_t)blk * kMphfDataWords + (bit >> 6), m = 1ull << (bit & 63);
+                uint64_t old = __atomic_fetch_or(&O[wi], m, __ATOMIC_RELAXED);
+                if (old & m) __atomic_fetch_or(&Cc[wi], m, __ATOMIC_RELAXED);
+            }
+        });
+        parallel_for(n_threads, occ.size(), [=](int, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) O[i] &= ~Cc[i];
+        });
+        // keys whose bit did not survive go to the next level
+        int nt = std::max(1, n_threads);
+        std::vector<std::vector<uint64_t>> parts(nt);
+        parallel_for(n_threads, rem, [&, O, K](int t, uint64_t b, uint64_t e) {
+            auto &out = parts[t];
+            for (uint64_t i = b; i < e; ++i) {
+                uint32_t blk, bit;
+                mphf_level_slot(K[i], L.seed, L.n_blocks, blk, bit);
+                uint64_t wi = (uint64_t)blk * kMphfDataWords + (bit >> 6);
+                if (!((O[wi] >> (bit & 63)) & 1)) out.push_back(K[i]);
+            }
+        });
+        next_keys.clear();
+        for (auto &p : parts) next_keys.insert(next_keys.end(), p.begin(), p.end());
+        // append interleaved blocks (headers filled below)
+        uint64_t base = blocks.size();
+        blocks.resize(base + nb * 8, 0);
+        uint64_t *B = blocks.data() + base;
+        parallel_for(n_threads, nb, [=](int, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+                uint64_t sub = 0, c = 0;
+                for (uint32_t j = 0; j < kMphfDataWords; ++j) {
+                    uint64_t wv = O[i * kMphfDataWords + j];
+                    B[i * 8 + 2 + j] = wv;
+                    sub |= c << (9 * j);
+                    c += popc64(wv);
+                }
+                B[i * 8 + 1] = sub;
+                B[i * 8 + 0] = c; // temporarily: ones in this block
+            }
+        });
+        levels.push_back(L);
+        total_blocks += nb;
+        keys.swap(next_keys);
+    }
+    // absolute ranks
+    uint64_t run = 0;
+    for (uint64_t i = 0; i < total_blocks; ++i) {
+        uint64_t c = blocks[i * 8];
+        blocks[i * 8] = run;
+        run += c;
+    }
+    if (run != n) {
+        set_error("MPHF: placed %llu of %llu keys", (unsigned long long)run, (unsigned long long)n);
+        return MZ_EINVAL;
+    }
+    if (blocks.empty()) blocks.assign(8, 0); // never hand out a null pointer
+    return MZ_OK;
+}
+
+// ------------------------------------------------------------------ UnitigSet
+static inline int base_code(unsigned char c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+    }
+}
+
+int UnitigSet::finish() {
+    if (k == 0 || k > 31) {
+        set_error("UnitigSet: k=%u unsupported (1..31)", k);
+        return MZ_EINVAL;
+    }
+    if (n_unitigs == 0 || total_len == 0) {
+        set_error("UnitigSet: empty");
+        return MZ_EEMPTY;
+    }
+    for (uint64_t i = 0; i < n_unitigs; ++i)
+        if (starts[i + 1] <= starts[i]) {
+            set_error("UnitigSet: unitig %llu is empty or offsets not increasing", (unsigned long long)i);
+            return MZ_EINVAL;
+        }
+    // accum_lens as Elias-Fano (unitig_set.rs:98), plus the blocked boundary vector
+    int rc = accum_lens.build(starts.data(), n_unitigs + 1, starts[n_unitigs]);
+    if (rc != MZ_OK) return rc;
+    uint64_t nb = (total_len >> kBvBasesPerBlockLog2) + 1;
+    bv_blocks.assign(nb * 8, 0);
+    for (uint64_t i = 1; i <= n_unitigs; ++i) { // bit at the last base of each unitig, unitig_set.rs:90-93
+        uint64_t p = starts[i] - 1;
+        uint64_t b = p >> kBvBasesPerBlockLog2, off = p & (kBvBasesPerBlock - 1);
+        bv_blocks[b * 8 + 4 + (off >> 6)] |= 1ull << (off & 63);
+    }
+    uint64_t uid = 0; // unitig holding the first base of the current block
+    for (uint64_t b = 0; b < nb; ++b) {
+        uint64_t first = b << kBvBasesPerBlockLog2;
+        uint64_t lastb = std::min<uint64_t>(first + kBvBasesPerBlock - 1, total_len - 1);
+        if (first >= total_len) { // tail block past the end: never probed by a valid position
+            bv_blocks[b * 8 + 0] = n_unitigs;
+            bv_blocks[b * 8 + 1] = total_len;
+            bv_blocks[b * 8 + 2] = total_len;
+            continue;
+        }
+        while (starts[uid + 1] <= first) ++uid;
+        uint64_t ul = uid;
+        while (starts[ul + 1] <= lastb) ++ul;
+        bv_blocks[b * 8 + 0] = uid;
+        bv_blocks[b * 8 + 1] = starts[uid];
+        bv_blocks[b * 8 + 2] = starts[ul + 1];
+    }
+    return MZ_OK;
+}
+
+int UnitigSet::from_packed(const uint64_t *words, uint64_t total_len_, const uint64_t *starts_, uint64_t n, uint32_t k_) {
+    if (!words || !starts_ || n == 0) {
+        set_error("UnitigSet::from_packed: null or empty input");
+        return MZ_EINVAL;
+    }
+    if (starts_[0] != 0 || starts_[n] != total_len_) {
+        set_error("UnitigSet::from_packed: starts[0] must be 0 and starts[n] == total_len");
+        return MZ_EINVAL;
+    }
+    k = k_;
+    total_len = total_len_;
+    n_unitigs = n;
+    uint64_t nw = (total_len + 31) / 32;
+    useq.assign(nw + 2, 0);
+    std::memcpy(useq.data(), words, nw * 8);
+    if (total_len & 31) useq[nw - 1] &= (1ull << (2 * (total_len & 31))) - 1; // zero the slack bits
+    starts.assign(starts_, starts_ + n + 1);
+    return finish();
+}
+
+// reference src/unitig_set.rs:74-106
+int UnitigSet::from_seqs(const char *const *seqs, uint64_t n, uint32_t k_) {
+    if (!seqs || n == 0) {
+        set_error("UnitigSet::from_seqs: no sequences");
+        return MZ_EEMPTY;
+    }
+    k = k_;
+    n_unitigs = n;
+    starts.assign(n + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) starts[i + 1] = starts[i] + std::strlen(seqs[i]);
+    total_len = starts[n];
+    useq.assign((total_len + 31) / 32 + 2, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t p = starts[i];
+        for (const char *s = seqs[i]; *s; ++s, ++p) {
+            int c = base_code((unsigned char)*s);
+            if (c < 0) {
+                set_error("UnitigSet::from_seqs: non-ACGT byte 0x%02x in sequence %llu", (unsigned char)*s, (unsigned long long)i);
+                return MZ_EINVAL;
+            }
+            useq[p >> 5] |= (uint64_t)c << (2 * (p & 31));
+        }
+    }
+    return finish();
+}
+
+// reference src/unitig_set.rs:119-165 (.cf_seg lines `id\tSEQ`; k from the cuttlefish json,
+// cuttlefish.rs:45-108, key "parameters info" / "k")
+int UnitigSet::from_cf_prefix(const std::string &prefix) {
+    std::ifstream js(prefix + ".json");
+    if (!js) {
+        set_error("cannot open %s.json", prefix.c_str());
+        return MZ_EIO;
+    }
+    std::string text((std::istreambuf_iterator<char>(js)), std::istreambuf_iterator<char>());
+    size_t p = text.find("\"parameters info\"");
+    size_t q = p == std::string::npos ? p : text.find("\"k\"", p);
+    if (q == std::string::npos) {
+        set_error("%s.json: no \"parameters info\".k", prefix.c_str());
+        return MZ_EIO;
+    }
+    q = text.find(':', q);
+    uint32_t kk = (uint32_t)std::strtoul(text.c_str() + q + 1, nullptr, 10);
+    std::ifstream seg(prefix + ".cf_seg");
+    if (!seg) {
+        set_error("cannot open %s.cf_seg", prefix.c_str());
+        return MZ_EIO;
+    }
+    std::vector<std::string> seqs;
+    std::string line;
+    while (std::getline(seg, line)) {
+        if (line.empty()) continue;
+        size_t tab = line.find('\t');
+        if (tab == std::string::npos) {
+            set_error("%s.cf_seg: cannot split line %zu", prefix.c_str(), seqs.size());
+            return MZ_EIO;
+        }
+        seqs.emplace_back(line.substr(tab + 1));
+    }
+    std::vector<const char *> ptrs;
+    for (auto &s : seqs) ptrs.push_back(s.c_str());
+    return from_seqs(ptrs.data(), ptrs.size(), kk);
+}
+
+// ------------------------------------------------------------------ SSHash builder
+struct Occ {
+    uint64_t word, pos;
+};
+static inline bool occ_less(const Occ &a, const Occ &b) { return a.word != b.word ? a.word < b.word : a.pos < b.pos; }
+
+// Parallel sort of (word,pos) tuples: partition by the top bits of `word`, then sort partitions.
+static void sort_occs(std::vector<Occ> &v, uint32_t word_bits, int n_threads) {
+    uint64_t n = v.size();
+    if (n_threads <= 1 || n < (1u << 16)) {
+        std::sort(v.begin(), v.end(), occ_less);
+        return;
+    }
+    uint32_t B = std::min<uint32_t>(word_bits, 12);
+    uint32_t shift = word_bits - B;
+    uint64_t nbk = 1ull << B;
+    int nt = n_threads;
+    std::vector<std::vector<uint64_t>> cnt(nt, std::vector<uint64_t>(nbk, 0));
+    const Occ *src = v.data();
+    parallel_for(nt, n, [&, src](int t, uint64_t b, uint64_t e) {
+        auto &c = cnt[t];
+        for (uint64_t i = b; i < e; ++i) c[src[i].word >> shift]++;
+    });
+    std::vector<uint64_t> bstart(nbk + 1, 0);
+    {
+        uint64_t acc = 0;
+        for (uint64_t b = 0; b < nbk; ++b) {
+            bstart[b] = acc;
+            for (int t = 0; t < nt; ++t) {
+                uint64_t c = cnt[t][b];
+                cnt[t][b] = acc;
+                acc += c;
+            }
+        }
+        bstart[nbk] = acc;
+    }
+    std::vector<Occ> tmp(n);
+    Occ *dst = tmp.data();
+    parallel_for(nt, n, [&, src, dst](int t, uint64_t b, uint64_t e) {
+        auto &c = cnt[t];
+        for (uint64_t i = b; i < e; ++i) dst[c[src[i].word >> shift]++] = src[i];
+    });
+    parallel_tasks(nt, nbk, [&, dst](int, uint64_t b) { std::sort(dst + bstart[b], dst + bstart[b + 1], occ_less); });
+    v.swap(tmp);
+}
+
+// Minimizer occurrences of one unitig (reference sshash.rs:100-143 via iter_canonical_minimizers):
+// for every k-mer p the canonical strand g* decides which w-mer hashes compete; the occurrence is
+// (w-mer word of g*, start of that w-mer on the FORWARD strand).  Consecutive duplicates are
+// dropped per strand class, as the reference's two filtered passes do.
+static void scan_unitig(const uint64_t *useq, uint64_t s, uint64_t e, uint32_t k, uint32_t w, uint64_t seed,
+                        std::vector<Occ> &out) {
+    if (e - s < k) return;
+    const uint32_t n_win = k - w + 1;
+    const uint64_t kmask = kmer_mask(k), wmask = kmer_mask(w);
+    uint64_t hf[64], hr[64], wf[64], wr[64];
+    uint64_t fwk = 0, rck = 0, fwm = 0, rcm = 0;
+    uint64_t fmin = 0, rmin = 0; // absolute w-mer start of the current argmins
+    bool have_f = false, have_r = false;
+    Occ prev_f{~0ull, ~0ull}, prev_r{~0ull, ~0ull};
+    for (uint64_t i = s; i < e; ++i) {
+        uint64_t c = (useq[i >> 5] >> (2 * (i & 31))) & 3;
+        fwk = ((fwk >> 2) | (c << (2 * (k - 1)))) & kmask;
+        rck = ((rck << 2) | (3 - c)) & kmask;
+        fwm = ((fwm >> 2) | (c << (2 * (w - 1)))) & wmask;
+        rcm = ((rcm << 2) | (3 - c)) & wmask;
+        if (i + 1 < s + w) continue;
+        uint64_t j = i + 1 - w; // w-mer start
+        uint32_t slot = (uint32_t)(j & 63);
+        wf[slot] = fwm;
+        wr[slot] = rcm;
+        hf[slot] = hash_mmer(fwm, seed);
+        hr[slot] = hash_mmer(rcm, seed);
+        if (i + 1 < s + k) { // window not full yet: keep running argmins
+            if (!have_f || hf[slot] < hf[fmin & 63]) { fmin = j; have_f = true; }
+            if (!have_r || hr[slot] <= hr[rmin & 63]) { rmin = j; have_r = true; }
+            continue;
+        }
+        uint64_t p = i + 1 - k; // k-mer start == first w-mer of the window
+        if (fmin < p) { // expired: rescan, leftmost minimum
+            fmin = p;
+            for (uint64_t q = p + 1; q <= j; ++q)
+                if (hf[q & 63] < hf[fmin & 63]) fmin = q;
+        } else if (hf[slot] < hf[fmin & 63]) fmin = j;
+        if (rmin < p) { // expired: rescan, rightmost minimum
+            rmin = p;
+            for (uint64_t q = p + 1; q <= j; ++q)
+                if (hr[q & 63] <= hr[rmin & 63]) rmin = q;
+        } else if (hr[slot] <= hr[rmin & 63]) rmin = j;
+        (void)n_win;
+        if (fwk <= rck) {
+            Occ o{wf[fmin & 63], fmin};
+            if (o.word != prev_f.word || o.pos != prev_f.pos) out.push_back(o);
+            prev_f = o;
+        } else {
+            Occ o{wr[rmin & 63], rmin};
+            if (o.word != prev_r.word || o.pos != prev_r.pos) out.push_back(o);
+            prev_r = o;
+        }
+    }
+}
+
+int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads) {
+    double t0 = now_s();
+    if (n_threads <= 0) n_threads = hw_threads();
+    if (w_ == 0 || w_ > unitigs.k) { // assert!(w <= unitigs.k()), sshash.rs:92
+        set_error("SSHash: minimizer size w=%u must be in 1..=k (k=%u)", w_, unitigs.k);
+        return MZ_EINVAL;
+    }
+    us = unitigs;
+    w = w_;
+    seed = seed_;
+    skew_param = skew_param_;
+    has_skew = false;
+    const uint32_t k = us.k;
+    const uint64_t *useq = us.useq.data();
+
+    // 1. collect minimizer occurrences (sshash.rs:94-143), unitigs sharded over threads by bases
+    int nt = n_threads;
+    std::vector<std::vector<Occ>> parts(nt);
+    {
+        std::vector<uint64_t> cut(nt + 1, us.n_unitigs);
+        cut[0] = 0;
+        for (int t = 1; t < nt; ++t) {
+            uint64_t target = us.total_len / nt * t;
+            cut[t] = std::lower_bound(us.starts.begin(), us.starts.end() - 1, target) - us.starts.begin();
+        }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                auto &out = parts[t];
+                for (uint64_t ui = cut[t]; ui < cut[t + 1]; ++ui)
+                    scan_unitig(useq, us.starts[ui], us.starts[ui + 1], k, w, seed, out);
+            });
+        for (auto &x : th) x.join();
+    }
+    std::vector<Occ> occs;
+    {
+        uint64_t tot = 0;
+        for (auto &p : parts) tot += p.size();
+        occs.reserve(tot);
+        for (auto &p : parts) {
+            occs.insert(occs.end(), p.begin(), p.end());
+            std::vector<Occ>().swap(p);
+        }
+    }
+    if (occs.empty()) {
+        set_error("SSHash: no k-mers (every unitig shorter than k=%u)", k);
+        return MZ_EEMPTY;
+    }
+    // 2. sort by (word,pos), drop exact duplicates, run-length -> minimizer set (sshash.rs:145-172)
+    sort_occs(occs, 2 * w, nt);
+    occs.erase(std::unique(occs.begin(), occs.end(), [](const Occ &a, const Occ &b) { return a.word == b.word && a.pos == b.pos; }),
+               occs.end());
+    uint64_t n_occ = occs.size();
+    std::vector<uint64_t> mm_set, range; // range[i] = first occurrence of minimizer i
+    for (uint64_t i = 0; i < n_occ; ++i)
+        if (i == 0 || occs[i].word != occs[i - 1].word) {
+            mm_set.push_back(occs[i].word);
+            range.push_back(i);
+        }
+    uint64_t n_mm = mm_set.size();
+    range.push_back(n_occ);
+    n_minimizers = n_mm;
+    // 3. MPHF over the minimizer set, gamma = 1.7 (sshash.rs:177)
+    int rc = mm.build(mm_set.data(), n_mm, 1.7, nt);
+    if (rc != MZ_OK) return rc;
+    // 4. bucket sizes in hash order -> prefix sums (sshash.rs:179-189)
+    std::vector<uint64_t> slot(n_mm), psum(n_mm + 1, 0);
+    {
+        MphfView mv = mm.view();
+        uint64_t *S = slot.data(), *P = psum.data();
+        const uint64_t *M = mm_set.data(), *R = range.data();
+        parallel_for(nt, n_mm, [=](int, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+                uint64_t h = 0;
+                mphf_lookup(mv, M[i], h);
+                S[i] = h;
+                P[h + 1] = R[i + 1] - R[i];
+            }
+        });
+        for (uint64_t i = 0; i < n_mm; ++i) psum[i + 1] += psum[i];
+    }
+    // 5. scatter positions into their buckets (sshash.rs:191-219)
+    std::vector<uint64_t> posv(n_occ);
+    uint64_t max_pos = 0;
+    {
+        uint64_t *PV = posv.data();
+        const uint64_t *S = slot.data(), *P = psum.data(), *R = range.data();
+        const Occ *O = occs.data();
+        parallel_for(nt, n_mm, [=](int, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+                uint64_t d = P[S[i]];
+                for (uint64_t j = R[i]; j < R[i + 1]; ++j) PV[d++] = O[j].pos;
+            }
+        });
+        max_pos = us.total_len; // every position < total_len
+    }
+    // 6. skew index (sshash.rs:221-296): k-mers around every occurrence of a heavy minimizer
+    if (skew_param != ~0ull) {
+        std::vector<std::vector<Occ>> sparts(nt);
+        const uint64_t *R = range.data();
+        const Occ *O = occs.data();
+        const uint64_t *bvb = us.bv_blocks.data();
+        uint64_t total_len = us.total_len, sp = skew_param;
+        parallel_for(nt, n_mm, [&, R, O, bvb, total_len, sp](int t, uint64_t b, uint64_t e) {
+            auto &out = sparts[t];
+            for (uint64_t i = b; i < e; ++i) {
+                if (R[i + 1] - R[i] <= sp) continue;
+                for (uint64_t j = R[i]; j < R[i + 1]; ++j) {
+                    uint64_t mp = O[j].pos;
+                    uint64_t start_pos = mp < (uint64_t)(k - w) ? 0 : mp - (k - w);
+                    for (uint64_t off = 0; off < (uint64_t)(k - w + 1); ++off) {
+                        uint64_t p = start_pos + off;
+                        if (p + k > total_len) break;
+                        UnitigSpan s = locate_unitig(bvb, p); // is_valid_useq_pos, unitig_set.rs:235-245
+                        if (p + k > s.end) continue;
+                        uint64_t x = read_kmer(useq, p, k), r = kmer_rc(x, k);
+                        out.push_back(Occ{x < r ? x : r, p});
+                    }
+                }
+            }
+        });
+        std::vector<Occ> tup;
+        for (auto &p : sparts) {
+            tup.insert(tup.end(), p.begin(), p.end());
+            std::vector<Occ>().swap(p);
+        }
+        sort_occs(tup, 2 * k, nt);
+        tup.erase(std::unique(tup.begin(), tup.end(), [](const Occ &a, const Occ &b) { return a.word == b.word; }), tup.end());
+        uint64_t sn = tup.size();
+        std::vector<uint64_t> km_set(sn), spos(sn, 0);
+        for (uint64_t i = 0; i < sn; ++i) km_set[i] = tup[i].word;
+        rc = skew.build(km_set.data(), sn, 1.7, nt);
+        if (rc != MZ_OK) return rc;
+        {
+            MphfView sv = skew.view();
+            uint64_t *SP = spos.data();
+            const Occ *T = tup.data();
+            parallel_for(nt, sn, [=](int, uint64_t b, uint64_t e) {
+                for (uint64_t i = b; i < e; ++i) {
+                    uint64_t h = 0;
+                    mphf_lookup(sv, T[i].word, h);
+                    SP[h] = T[i].pos;
+                }
+            });
+        }
+        skew_pos.assign(spos.data(), sn, us.total_len, nt);
+        has_skew = true;
+    }
+    // 7. finish (sshash.rs:310-329): Elias-Fano the prefix sums, bit-pack the positions
+    rc = buckets.build(psum.data(), n_mm + 1, psum[n_mm]);
+    if (rc != MZ_OK) return rc;
+    pos.assign(posv.data(), n_occ, max_pos, nt);
+    build_seconds = now_s() - t0;
+    return MZ_OK;
+}
+
+IndexView SSHashHost::view() const {
+    IndexView v{};
+    v.k = us.k;
+    v.w = w;
+    v.seed = seed;
+    v.total_len = us.total_len;
+    v.n_unitigs = us.n_unitigs;
+    v.skew_param = skew_param;
+    v.useq = us.useq.data();
+    v.bv_blocks = us.bv_blocks.data();
+    v.mm = mm.view();
+    v.buckets = buckets.view();
+    v.pos = pos.w.data();
+    v.pos_width = pos.width;
+    v.has_skew = has_skew ? 1 : 0;
+    if (has_skew) {
+        v.skew = skew.view();
+        v.skew_pos = skew_pos.w.data();
+        v.skew_pos_width = skew_pos.width;
+    }
+    v.starts = us.starts.data();
+    return v;
+}
+
+// sshash.rs:341-358 (the MPHF term is the exact size of ours, not a bincode estimate)
+uint64_t SSHashHost::num_bits() const {
+    uint64_t b = 64 + us.num_bits() + buckets.num_bits() + pos.num_bits() + mm.num_bits();
+    if (has_skew) b += skew.num_bits() + skew_pos.num_bits();
+    return b;
+}
+
+// ------------------------------------------------------------------ flat file
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '1'};
+template <class T>
+static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
+template <class T>
+static void putv(std::ofstream &f, const std::vector<T> &v) {
+    uint64_t n = v.size();
+    put(f, n);
+    f.write((const char *)v.data(), n * sizeof(T));
+}
+template <class T>
+static bool get(std::ifstream &f, T &x) { return (bool)f.read((char *)&x, sizeof x); }
+template <class T>
+static bool getv(std::ifstream &f, std::vector<T> &v) {
+    uint64_t n;
+    if (!get(f, n)) return false;
+    v.resize(n);
+    return (bool)f.read((char *)v.data(), n * sizeof(T));
+}
+static void put_mphf(std::ofstream &f, const Mphf &m) { put(f, m.n_keys); putv(f, m.blocks); putv(f, m.levels); }
+static bool get_mphf(std::ifstream &f, Mphf &m) { return get(f, m.n_keys) && getv(f, m.blocks) && getv(f, m.levels); }
+static void put_ef(std::ofstream &f, const EFVector &e) { put(f, e.u); put(f, e.n); put(f, e.n_high_bits); put(f, e.l); putv(f, e.high); putv(f, e.sel); putv(f, e.low); }
+static bool get_ef(std::ifstream &f, EFVector &e) { return get(f, e.u) && get(f, e.n) && get(f, e.n_high_bits) && get(f, e.l) && getv(f, e.high) && getv(f, e.sel) && getv(f, e.low); }
+static void put_pv(std::ofstream &f, const PackedVec &p) { put(f, p.n); put(f, p.width); putv(f, p.w); }
+static bool get_pv(std::ifstream &f, PackedVec &p) { return get(f, p.n) && get(f, p.width) && getv(f, p.w); }
+
+int SSHashHost::save(const std::string &path) const {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) {
+        set_error("cannot create %s", path.c_str());
+        return MZ_EIO;
+    }
+    f.write(kMagic, 8);
+    put(f, us.k); put(f, w); put(f, seed); put(f, skew_param); put(f, us.total_len); put(f, us.n_unitigs); put(f, n_minimizers);
+    uint32_t hs = has_skew ? 1 : 0;
+    put(f, hs);
+    putv(f, us.useq); putv(f, us.starts); putv(f, us.bv_blocks); put_ef(f, us.accum_lens);
+    put_mphf(f, mm); put_ef(f, buckets); put_pv(f, pos);
+    if (has_skew) { put_mphf(f, skew); put_pv(f, skew_pos); }
+    return f ? MZ_OK : (set_error("short write to %s", path.c_str()), MZ_EIO);
+}
+
+int SSHashHost::load(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    char magic[8];
+    if (!f || !f.read(magic, 8) || std::memcmp(magic, kMagic, 8) != 0) {
+        set_error("%s: not a mazu_amd SSHash file", path.c_str());
+        return MZ_EIO;
+    }
+    uint32_t hs = 0;
+    bool ok = get(f, us.k) && get(f, w) && get(f, seed) && get(f, skew_param) && get(f, us.total_len) && get(f, us.n_unitigs) &&
+              get(f, n_minimizers) && get(f, hs) && getv(f, us.useq) && getv(f, us.starts) && getv(f, us.bv_blocks) &&
+              get_ef(f, us.accum_lens) && get_mphf(f, mm) && get_ef(f, buckets) && get_pv(f, pos);
+    has_skew = hs != 0;
+    if (ok && has_skew) ok = get_mphf(f, skew) && get_pv(f, skew_pos);
+    if (!ok) {
+        set_error("%s: truncated", path.c_str());
+        return MZ_EIO;
+    }
+    return MZ_OK;
+}
+
+} // namespace mz

@@ -1,0 +1,100 @@
+// mz_host.hpp -- host-side owner of the index layout (the role BASELINE.json gives to
+// "Rust host code"): UnitigSet, Elias-Fano, rank-interleaved MPHF and the SSHash builder.
+// Follows the construction steps of reference src/kphf/sshash.rs:86-329 but lays every
+// structure out for 64-byte-line gathers on MI355X ("Data layout in HBM").
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mz_common.hpp"
+
+namespace mz {
+
+int hw_threads();
+
+// fixed-width packed integers (the reference's IntVector::pack, sshash.rs:314-315)
+struct PackedVec {
+    std::vector<uint64_t> w; // padded with 2 words
+    uint64_t n = 0;
+    uint32_t width = 1;
+    void assign(const uint64_t *xs, uint64_t n_, uint64_t max_value, int n_threads);
+    uint64_t get(uint64_t i) const { return read_packed(w.data(), i, width); }
+    uint64_t num_bits() const { return n * width; }
+};
+
+// Elias-Fano monotone sequence (reference src/elias_fano.rs:21-122): l = max(1, msb(u/n)),
+// high part in unary with n + (u >> l) bits, low part packed.  `sel` replaces simple-sds'
+// select support with one sampled position per 2^kEfSelLog2 ones.
+struct EFVector {
+    uint64_t u = 0, n = 0, n_high_bits = 0;
+    uint32_t l = 1;
+    std::vector<uint64_t> high, sel, low;
+    // returns MZ_OK, MZ_ENOTMONOTONE or MZ_EEMPTY (Error::EFNotMonotone / EFEmpty)
+    int build(const uint64_t *xs, uint64_t n_, uint64_t u_);
+    EfView view() const { return EfView{high.data(), sel.data(), low.data(), n, (uint64_t)high.size(), l, 0}; }
+    uint64_t get(uint64_t i) const { return ef_get(view(), i); }
+    uint64_t len() const { return n; }
+    uint64_t num_bits() const { return 3 * 64 + n_high_bits + n * l; } // elias_fano.rs:31-33
+};
+
+// Minimal perfect hash in the BBHash/boomphf family (reference uses boomphf::Mphf, gamma 1.7,
+// sshash.rs:177,280) stored as rank-interleaved 64-byte blocks.
+struct Mphf {
+    std::vector<uint64_t> blocks;
+    std::vector<MphfLevel> levels;
+    uint64_t n_keys = 0;
+    // keys must be distinct; returns MZ_OK or MZ_EINVAL (too many levels)
+    int build(const uint64_t *keys, uint64_t n, double gamma, int n_threads);
+    MphfView view() const { return MphfView{blocks.data(), levels.data(), (uint32_t)levels.size(), 0, n_keys}; }
+    bool try_hash(uint64_t key, uint64_t &idx) const { return mphf_lookup(view(), key, idx); }
+    uint64_t num_bits() const { return blocks.size() * 64 + levels.size() * sizeof(MphfLevel) * 8; }
+};
+
+// UnitigSet (reference src/unitig_set.rs:30-36)
+struct UnitigSet {
+    uint32_t k = 0;
+    uint64_t total_len = 0, n_unitigs = 0;
+    std::vector<uint64_t> useq;      // 2-bit packed + 2 pad words
+    std::vector<uint64_t> starts;    // n_unitigs + 1 (plain copy of accum_lens)
+    EFVector accum_lens;             // as in the reference
+    std::vector<uint64_t> bv_blocks; // boundary bit vector, rank/select-interleaved blocks
+
+    int from_packed(const uint64_t *words, uint64_t total_len_, const uint64_t *starts_, uint64_t n, uint32_t k_);
+    int from_seqs(const char *const *seqs, uint64_t n, uint32_t k_);
+    int from_cf_prefix(const std::string &prefix);
+    uint64_t n_kmers() const { return total_len - (uint64_t)k * n_unitigs + n_unitigs; } // :212-214
+    uint64_t unitig_len(uint64_t i) const { return accum_lens.get(i + 1) - accum_lens.get(i); } // :178-180
+    uint64_t unitig_start_pos(uint64_t i) const { return accum_lens.get(i); }
+    uint64_t pos_to_id(uint64_t pos) const { return locate_unitig(bv_blocks.data(), pos).id; } // :185-187
+    uint64_t num_bits() const { return 64 + total_len * 2 + accum_lens.num_bits() + total_len; } // :41-47
+private:
+    int finish();
+};
+
+// SSHash (reference src/kphf/sshash.rs:39-57)
+struct SSHashHost {
+    UnitigSet us;
+    uint32_t w = 0;
+    uint64_t seed = 0;
+    uint64_t skew_param = ~0ull;
+    Mphf mm;          // mphf
+    EFVector buckets; // occs_prefix_sum
+    PackedVec pos;    // pos
+    bool has_skew = false;
+    Mphf skew;        // skew_index.mphf
+    PackedVec skew_pos;
+    uint64_t n_minimizers = 0;
+    double build_seconds = 0;
+
+    int build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads);
+    IndexView view() const;
+    uint64_t num_bits() const;
+    int save(const std::string &path) const;
+    int load(const std::string &path);
+};
+
+void set_error(const char *fmt, ...);
+const char *last_error();
+
+} // namespace mz

@@ -81,8 +81,8 @@ class OracleSSHash:
         self.k_ = k
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_free(self.h)
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.orc_free(self.h)
             self.h = None
 
     # K2U trait accessors (kphf/mod.rs:58-67)
