@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "mz_device.hpp"
 
@@ -24,16 +25,35 @@ namespace mz {
 
 constexpr int kBlock = 256;
 
-// one atomic per wavefront: lanes ballot, the first active lane adds the popcounts
-__device__ __forceinline__ void wave_tally(mz_counts *counts, bool hit, bool miss, bool skipped) {
-    unsigned long long bh = __ballot(hit), bm = __ballot(miss), bs = __ballot(skipped);
-    unsigned long long active = __ballot(1);
-    if (counts && (__lane_id() == (unsigned)(__ffsll((long long)active) - 1))) {
-        if (bh) atomicAdd((unsigned long long *)&counts->n_hit, (unsigned long long)__popcll(bh));
-        if (bm) atomicAdd((unsigned long long *)&counts->n_miss, (unsigned long long)__popcll(bm));
-        if (bs) atomicAdd((unsigned long long *)&counts->n_skipped, (unsigned long long)__popcll(bs));
+// Hit / miss / skipped tallies.  Lanes ballot and every wave keeps wave-uniform popcounts in
+// registers for the whole kernel; at the end the waves of a workgroup combine them in LDS and ONE
+// lane issues the global atomics.  (A device-scope atomic on one address costs ~12 ns, so a
+// per-wave-per-iteration tally would cap the whole kernel at ~5 G queries/s on its own.)
+struct Tally {
+    uint32_t hit = 0, miss = 0, skipped = 0;
+    __device__ __forceinline__ void add(bool h, bool m, bool s) {
+        hit += (uint32_t)__popcll(__ballot(h));
+        miss += (uint32_t)__popcll(__ballot(m));
+        skipped += (uint32_t)__popcll(__ballot(s));
     }
-}
+    // call once per thread at the end of the kernel, from uniform control flow
+    __device__ __forceinline__ void flush(mz_counts *counts) {
+        __shared__ uint32_t s_tally[3];
+        if (threadIdx.x == 0) { s_tally[0] = 0; s_tally[1] = 0; s_tally[2] = 0; }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            if (hit) atomicAdd(&s_tally[0], hit);
+            if (miss) atomicAdd(&s_tally[1], miss);
+            if (skipped) atomicAdd(&s_tally[2], skipped);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && counts) {
+            if (s_tally[0]) atomicAdd((unsigned long long *)&counts->n_hit, (unsigned long long)s_tally[0]);
+            if (s_tally[1]) atomicAdd((unsigned long long *)&counts->n_miss, (unsigned long long)s_tally[1]);
+            if (s_tally[2]) atomicAdd((unsigned long long *)&counts->n_skipped, (unsigned long long)s_tally[2]);
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------
 // K: batched point queries (mz_sshash_k2u_batch_device)
@@ -41,11 +61,290 @@ __device__ __forceinline__ void wave_tally(mz_counts *counts, bool hit, bool mis
 __global__ __launch_bounds__(kBlock) void k2u_batch_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
                                                            mz_k2upos *__restrict__ out, mz_counts *counts) {
     uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    Tally tally;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         mz_k2upos r = lookup(ix, fw_words[i]);
         out[i] = r;
-        wave_tally(counts, r.match != MZ_NO_MATCH, r.match == MZ_NO_MATCH, false);
+        tally.add(r.match != MZ_NO_MATCH, r.match == MZ_NO_MATCH, false);
     }
+    tally.flush(counts);
+}
+
+
+// ------------------------------------------------------------------------------------
+// K: LDS-staged tile kernel -- the production k2u path.
+//
+// A workgroup owns a tile of kTileQ queries whose state lives in LDS; the dependent chain of
+// sshash.rs:471-554 is cut into stages separated by barriers, and between stages the work is
+// re-compacted with wavefront ballots so that every vector memory instruction is issued by
+// (nearly) full waves, with several independent gathers in flight per lane:
+//   S0  canonical encode + minimizer (ALU only)                      dense over queries
+//   S1  MPHF probe, one level (pair) per round; unresolved keys are ballot-compacted into an
+//       LDS list for the next round (geometric shrink)               dense over pending keys
+//   S2  Elias-Fano get(h), get(h+1) -> bucket range                  dense over queries
+//   S3  bucket entries flattened by an LDS prefix sum: one (query, entry) item per lane
+//       iteration: packed pos -> two candidate k-mers -> verify -> unitig locate + boundary
+//       check; the winner is kept with an LDS atomicMin in bucket order (A before B)
+//   S4  heavy buckets: skew MPHF (same level loop) -> packed pos -> verify
+//   S5  results materialised from the winning position and stored as coalesced 16-byte records
+// ------------------------------------------------------------------------------------
+constexpr int kQpt = 4;                  // queries per thread
+constexpr int kTileQ = kBlock * kQpt;    // queries per tile
+constexpr unsigned long long kBestNone = ~0ull;
+constexpr uint32_t kPosBits = 36, kNMiss = 0xFFFFFFFFu, kNSkew = 0xFFFFFFFEu;
+
+struct TileLds {
+    uint64_t fw[kTileQ];               // forward word of the query
+    uint64_t slot[kTileQ];             // minimizer word -> bucket id h -> bucket start (skew: canonical word -> slot)
+    unsigned long long best[kTileQ];   // (bucket order key << 37) | (twin << 36) | global k-mer position
+    uint32_t n[kTileQ];                // bucket size, kNSkew, or kNMiss
+    uint32_t eoff[kTileQ + 1];         // exclusive prefix sum of bucket sizes
+    uint16_t list_a[kTileQ], list_b[kTileQ];
+    uint8_t off[kTileQ];               // minimizer offset inside g*
+    uint32_t cnt_a, cnt_b, cnt_skew, wave_tot[kBlock / 64];
+};
+
+// append `idx` of the lanes with pred to an LDS list (one LDS atomic per wave)
+__device__ __forceinline__ void wave_push(uint16_t *list, uint32_t *cnt, bool pred, uint32_t idx) {
+    unsigned long long b = __ballot(pred);
+    if (b == 0) return;
+    unsigned lane = __lane_id();
+    unsigned leader = (unsigned)(__ffsll((long long)b) - 1);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(cnt, (uint32_t)__popcll(b));
+    base = __shfl(base, (int)leader);
+    if (pred) list[base + __popcll(b & ((1ull << lane) - 1))] = (uint16_t)idx;
+}
+
+struct MphfProbe { // one level: issue the loads first, evaluate later
+    uint64_t word, h0, h1;
+    uint32_t dw, bi;
+};
+__device__ __forceinline__ MphfProbe mphf_issue(const MphfView &m, const MphfLevel &L, uint64_t key) {
+    uint32_t blk, bit;
+    mphf_level_slot(key, L.seed, L.n_blocks, blk, bit);
+    const uint64_t *b = m.blocks + (L.block_off + blk) * 8;
+    MphfProbe p;
+    p.dw = bit >> 6;
+    p.bi = bit & 63;
+    p.word = b[2 + p.dw];
+    p.h0 = b[0];
+    p.h1 = b[1];
+    return p;
+}
+__device__ __forceinline__ bool mphf_eval(const MphfProbe &p, uint64_t &idx) {
+    if (!((p.word >> p.bi) & 1)) return false;
+    uint64_t below = p.bi ? (p.word & ((1ull << p.bi) - 1)) : 0;
+    idx = p.h0 + ((p.h1 >> (9 * p.dw)) & 511u) + popc64(below);
+    return true;
+}
+
+// S1 / S4: resolve slot[i] (key) -> MPHF index for the items of list_a[0..cnt_a); items that fall
+// through every level get n[i] = kNMiss.  `dense_first` == all kTileQ items (level 0, no list).
+__device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool dense_first, uint32_t n_valid) {
+    const uint32_t t = threadIdx.x;
+    uint32_t lv = 0;
+    if (dense_first) {
+        if (m.n_levels == 0) {
+            for (int q = 0; q < kQpt; ++q) { uint32_t i = q * kBlock + t; if (i < n_valid) S.n[i] = kNMiss; }
+            return;
+        }
+        const MphfLevel L = m.levels[0];
+        MphfProbe pr[kQpt];
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * kBlock + t;
+            pr[q] = mphf_issue(m, L, i < n_valid ? S.slot[i] : 0);
+        }
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * kBlock + t;
+            uint64_t idx;
+            bool hit = mphf_eval(pr[q], idx);
+            if (hit && i < n_valid) S.slot[i] = idx;
+            wave_push(S.list_a, &S.cnt_a, !hit && i < n_valid, i);
+        }
+        lv = 1;
+    }
+    uint16_t *cur = S.list_a, *nxt = S.list_b;
+    uint32_t *ccur = &S.cnt_a, *cnxt = &S.cnt_b;
+    for (;;) {
+        __syncthreads();
+        const uint32_t count = *ccur;
+        if (count == 0) break;
+        if (lv >= m.n_levels) { // fell through every level: boomphf try_hash -> None
+            for (uint32_t j = t; j < count; j += kBlock) S.n[cur[j]] = kNMiss;
+            __syncthreads();
+            if (t == 0) *ccur = 0;
+            break;
+        }
+        const bool two = lv + 1 < m.n_levels; // probe two levels per round (speculative second)
+        const MphfLevel L0 = m.levels[lv], L1 = m.levels[two ? lv + 1 : lv];
+        for (uint32_t j = t; j < ((count + 63) & ~63u); j += kBlock) {
+            bool act = j < count;
+            uint32_t i = act ? cur[j] : 0;
+            uint64_t key = S.slot[i];
+            MphfProbe p0 = mphf_issue(m, L0, key), p1 = mphf_issue(m, L1, key);
+            uint64_t idx;
+            bool hit = mphf_eval(p0, idx) || (two && mphf_eval(p1, idx));
+            if (act && hit) S.slot[i] = idx;
+            wave_push(nxt, cnxt, act && !hit, i);
+        }
+        lv += two ? 2 : 1;
+        __syncthreads();
+        if (t == 0) *ccur = 0;
+        uint16_t *tl = cur; cur = nxt; nxt = tl;
+        uint32_t *tc = ccur; ccur = cnxt; cnxt = tc;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
+                                                          mz_k2upos *__restrict__ out, mz_counts *counts) {
+    __shared__ TileLds S;
+    const uint32_t t = threadIdx.x, k = ix.k, w = ix.w;
+    const uint64_t kmask = kmer_mask(k);
+    const uint64_t n_tiles = (n + kTileQ - 1) / kTileQ;
+    Tally tally;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t base = tile * kTileQ;
+        const uint32_t n_valid = (uint32_t)(n - base < (uint64_t)kTileQ ? n - base : (uint64_t)kTileQ);
+        if (t == 0) { S.cnt_a = 0; S.cnt_b = 0; S.cnt_skew = 0; }
+        // ---- S0: canonical encode + minimizer
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * kBlock + t;
+            uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
+            uint64_t rc = kmer_rc(fw, k);
+            Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
+            S.fw[i] = fw;
+            S.slot[i] = mn.word;
+            S.off[i] = (uint8_t)mn.offset;
+            S.best[i] = kBestNone;
+            S.n[i] = 0;
+        }
+        __syncthreads();
+        // ---- S1: minimizer MPHF
+        tile_mphf(S, ix.mm, true, n_valid);
+        // ---- S2: bucket range from the Elias-Fano prefix sums
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * kBlock + t;
+            bool act = i < n_valid && S.n[i] != kNMiss;
+            bool heavy = false;
+            if (act) {
+                uint64_t ps, pe;
+                ef_get_pair(ix.buckets, S.slot[i], ps, pe);
+                uint64_t cnt = pe - ps;
+                heavy = cnt > ix.skew_param;                        // sshash.rs:486-490
+                S.slot[i] = ps;
+                S.n[i] = heavy ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
+            }
+            wave_push(S.list_b, &S.cnt_skew, heavy, i);
+        }
+        __syncthreads();
+        // ---- S3: flatten bucket entries (exclusive scan of n over the tile, blocked by thread)
+        {
+            uint32_t v[kQpt], sum = 0;
+#pragma unroll
+            for (int q = 0; q < kQpt; ++q) {
+                uint32_t nn = S.n[t * kQpt + q];
+                v[q] = sum;
+                sum += (nn >= kNSkew) ? 0u : nn;
+            }
+            uint32_t incl = sum;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t o = __shfl_up(incl, d);
+                if ((int)(t & 63) >= d) incl += o;
+            }
+            if ((t & 63) == 63) S.wave_tot[t >> 6] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+            for (uint32_t wv = 0; wv < (t >> 6); ++wv) wbase += S.wave_tot[wv];
+            uint32_t excl = wbase + incl - sum;
+#pragma unroll
+            for (int q = 0; q < kQpt; ++q) S.eoff[t * kQpt + q] = excl + v[q];
+            if (t == kBlock - 1) S.eoff[kTileQ] = excl + sum;
+        }
+        __syncthreads();
+        {
+            const uint32_t E = S.eoff[kTileQ];
+            const uint64_t last_km_start = ix.total_len - k;
+            for (uint32_t e = t; e < E; e += kBlock) {
+                // owner item: largest i with eoff[i] <= e
+                uint32_t lo = 0, hi = kTileQ;
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (S.eoff[mid] <= e) lo = mid; else hi = mid;
+                }
+                const uint32_t i = lo, j = e - S.eoff[i];
+                const uint64_t mm_pos = read_packed(ix.pos, S.slot[i] + j, ix.pos_width);   // sshash.rs:495
+                const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+                const uint64_t off_a = S.off[i], off_b = k - off_a - w;                  // :493
+                const bool va = mm_pos >= off_a && mm_pos - off_a <= last_km_start;       // :498
+                const bool vb = mm_pos >= off_b && mm_pos - off_b <= last_km_start;       // :527
+                const uint64_t pa = mm_pos - off_a, pb = mm_pos - off_b;
+                const uint64_t ka = va ? read_kmer(ix.useq, pa, k) : 0, kb = vb ? read_kmer(ix.useq, pb, k) : 0;
+                const uint32_t ma = va ? word_equivalency(fw, rc, ka) : MZ_NO_MATCH;
+                const uint32_t mb = vb ? word_equivalency(fw, rc, kb) : MZ_NO_MATCH;
+                const uint64_t jj = j < 0x3FFFFFFu ? j : 0x3FFFFFFu;
+                if (ma != MZ_NO_MATCH) {
+                    UnitigSpan s = locate_unitig(ix.bv_blocks, pa);
+                    if (pa + k <= s.end)                                                  // :509-514
+                        atomicMin(&S.best[i], ((jj * 2) << (kPosBits + 1)) | ((uint64_t)(ma == MZ_TWIN_MATCH) << kPosBits) | pa);
+                }
+                if (mb != MZ_NO_MATCH) {
+                    UnitigSpan s = locate_unitig(ix.bv_blocks, pb);
+                    if (pb + k <= s.end)                                                  // :538-541
+                        atomicMin(&S.best[i], ((jj * 2 + 1) << (kPosBits + 1)) | ((uint64_t)(mb == MZ_TWIN_MATCH) << kPosBits) | pb);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- S4: heavy buckets go through the skew index (sshash.rs:415-433)
+        if (S.cnt_skew != 0) { // uniform
+            const uint32_t ns = S.cnt_skew;
+            __syncthreads();
+            if (ix.has_skew) {
+                for (uint32_t j = t; j < ns; j += kBlock) {
+                    uint32_t i = S.list_b[j];
+                    uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+                    S.slot[i] = fw < rc ? fw : rc;
+                    S.list_a[j] = (uint16_t)i;
+                    S.eoff[j] = i; // eoff is free now: remember the heavy items across the level loop
+                }
+                if (t == 0) { S.cnt_a = ns; S.cnt_b = 0; }
+                __syncthreads();
+                tile_mphf(S, ix.skew, false, n_valid);
+                for (uint32_t j = t; j < ns; j += kBlock) {
+                    uint32_t i = S.eoff[j];
+                    if (S.n[i] == kNMiss) continue;
+                    uint64_t p = read_packed(ix.skew_pos, S.slot[i], ix.skew_pos_width);
+                    uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+                    uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
+                    if (mt != MZ_NO_MATCH) S.best[i] = ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- S5: materialise results, coalesced 16-byte stores, one tally atomic per wave
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * kBlock + t;
+            bool act = i < n_valid;
+            unsigned long long b = S.best[i];
+            mz_k2upos r = make_none();
+            if (act && b != kBestNone) {
+                uint64_t p = b & ((1ull << kPosBits) - 1);
+                UnitigSpan s = locate_unitig(ix.bv_blocks, p);
+                r = make_hit(s, p, ((b >> kPosBits) & 1) ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH);
+            }
+            if (act) out[base + i] = r;
+            tally.add(act && r.match != MZ_NO_MATCH, act && r.match == MZ_NO_MATCH, false);
+        }
+        __syncthreads();
+    }
+    tally.flush(counts);
 }
 
 // hits only, compacted per wavefront with a ballot + prefix popcount (K7)
@@ -139,8 +438,8 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
     // w-mer hashes of the tile, both strands (positions t and, for the first k-w lanes, kTile+t)
     for (uint32_t j = t; j < kTile + n_win - 1; j += kBlock) {
         uint64_t m = spread_bits(plane_window(plane_lo, j, w)) | (spread_bits(plane_window(plane_hi, j, w)) << 1);
-        hf[j] = hash_mmer(m, ix.seed);
-        hr[j] = hash_mmer(kmer_rc(m, w), ix.seed);
+        hf[j] = hash_mmer(m, ix.seed, w);
+        hr[j] = hash_mmer(kmer_rc(m, w), ix.seed, w);
     }
     __syncthreads();
 
@@ -188,8 +487,9 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
         }
         out[out_idx] = res;
     }
-    wave_tally(counts, has_window && valid && res.match != MZ_NO_MATCH, has_window && valid && res.match == MZ_NO_MATCH,
-               has_window && !valid);
+    Tally tally;
+    tally.add(has_window && valid && res.match != MZ_NO_MATCH, has_window && valid && res.match == MZ_NO_MATCH, has_window && !valid);
+    tally.flush(counts);
 }
 
 // ------------------------------------------------------------------------------------
@@ -339,11 +639,26 @@ static unsigned grid_for(const DeviceIndex &d, uint64_t n_items, unsigned blocks
     return (unsigned)std::max<uint64_t>(1, std::min(need, cap));
 }
 
+static bool use_v1_kernel() {
+    static const bool v = [] { const char *e = getenv("MZ_K2U_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
+    return v;
+}
+
 int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
                      hipStream_t stream) {
     if (n == 0) return MZ_OK;
     MZ_HIP_CHECK(hipSetDevice(d.device));
-    hipLaunchKernelGGL(k2u_batch_kernel, dim3(grid_for(d, n, 32)), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
+    if (d.view.total_len >= (1ull << kPosBits)) {
+        set_error("unitig set longer than 2^%u bases is not supported by the tile kernel", kPosBits);
+        return MZ_EINVAL;
+    }
+    if (use_v1_kernel()) { // lane-per-query kernel (kept for A/B measurements)
+        hipLaunchKernelGGL(k2u_batch_kernel, dim3(grid_for(d, n, 32)), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
+    } else {
+        uint64_t n_tiles = (n + kTileQ - 1) / kTileQ;
+        unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)d.n_cu * 16));
+        hipLaunchKernelGGL(k2u_tile_kernel, dim3(grid), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
+    }
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;
 }

@@ -444,8 +444,8 @@ static void scan_unitig(const uint64_t *useq, uint64_t s, uint64_t e, uint32_t k
         uint32_t slot = (uint32_t)(j & 63);
         wf[slot] = fwm;
         wr[slot] = rcm;
-        hf[slot] = hash_mmer(fwm, seed);
-        hr[slot] = hash_mmer(rcm, seed);
+        hf[slot] = hash_mmer(fwm, seed, w);
+        hr[slot] = hash_mmer(rcm, seed, w);
         if (i + 1 < s + k) { // window not full yet: keep running argmins
             if (!have_f || hf[slot] < hf[fmin & 63]) { fmin = j; have_f = true; }
             if (!have_r || hr[slot] <= hr[rmin & 63]) { rmin = j; have_r = true; }
