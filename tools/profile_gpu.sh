@@ -3,11 +3,11 @@
 # usage: tools/profile_gpu.sh <workload> <tag> [steps]
 # Counters are collected in their own runs (one --pmc set per run), never together with tracing.
 set -u
-W=${1:-s-eighth}; TAG=${2:-r01}; STEPS=${3:-5}
+W=${1:-s-eighth}; TAG=${2:-r01}; STEPS=${3:-5}; EXTRA=${4:-}
 OUT=gpurun_out/prof_${TAG}_${W}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --workload $W --steps $STEPS --warmup 1 --no-cpu-baseline"
+BENCH="python3 bench.py --workload $W --steps $STEPS --warmup 1 --no-cpu-baseline $EXTRA"
 run_pmc() { # name counters...
   local name=$1; shift
   timeout -k 10 500 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -o pmc -- $BENCH > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || echo "pmc $name failed rc=$?"
