@@ -90,8 +90,22 @@ def main():
     starts_h = us["starts"].cpu().numpy().view(np.uint64)
     t_gen = time.time() - t0
     t0 = time.time()
-    uset = M.UnitigSet.from_packed(words_h, us["total_len"], starts_h, k)
-    ix = M.SSHash.from_unitig_set(uset, args.w, args.skew, args.seed)
+    shared = None
+    if world > 1:  # one host build per node: rank 0 builds and lends the flat index file through /dev/shm
+        shared = f"/dev/shm/mazu_amd_bench_{os.environ.get('MASTER_PORT', '0')}_{args.workload}.mzsshash"
+    if rank == 0:
+        uset = M.UnitigSet.from_packed(words_h, us["total_len"], starts_h, k)
+        ix = M.SSHash.from_unitig_set(uset, args.w, args.skew, args.seed)
+        del uset
+        if shared:
+            ix.save(shared)
+    if world > 1:
+        dist.barrier()
+        if rank != 0:
+            ix = M.SSHash.load(shared)
+        dist.barrier()
+        if rank == 0:
+            os.unlink(shared)
     t_build = time.time() - t0
     t0 = time.time()
     ix.to_device(local_rank)
@@ -169,7 +183,7 @@ def main():
             "hit_fraction": round(n_hit / total_q, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k2u_batch_kernel", "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
+                         "kernel": "k2u_batch_kernel(v1)" if os.environ.get("MZ_K2U_KERNEL", "") == "v1" else "k2u_tile_kernel", "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_kmer": B_ALG},
             "build": {"gen_s": round(t_gen, 2), "host_build_s": round(t_build, 2), "upload_s": round(t_upload, 2),
                       "bits_per_kmer": round(ix.num_bits() / ix.n_kmers(), 2)},

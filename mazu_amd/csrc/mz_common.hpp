@@ -202,6 +202,79 @@ struct EfView {
     uint32_t pad;
 };
 
+
+// Partitioned Elias-Fano for the bucket prefix sums (the reference's occs_prefix_sum EFVector,
+// sshash.rs:46, elias_fano.rs) re-blocked so that get(i) and get(i+1) cost ONE 64-byte line:
+// block j holds elements [64j, 64j+64] (65 values, the last shared with block j+1).
+//   w0      : bits 0..39 base = x[64j]; bits 40..45 l (low width); bit 63 = overflow
+//   w1..    : high parts of elements 1..64 in unary (element t sets bit (r_t >> l) + t-1),
+//             r_t = x[64j+t] - base
+//   w7-p    : bit plane p (p < l) of the low parts, bit t-1 = bit p of r_t's low part
+// A block whose encoding does not fit 448 bits is flagged and its 65 values are stored plain in
+// `ovf` (w0 bits 0..39 = first word of the record).
+constexpr uint32_t kBefShift = 6, kBefSpan = 64, kBefMaxL = 6;
+struct BefView {
+    const uint64_t *blocks; // 8 words per block
+    const uint64_t *ovf;    // 65 words per overflowed block
+    uint64_t n;             // number of elements
+};
+MZ_HD void bef_get_pair(const BefView &e, uint64_t i, uint64_t &v0, uint64_t &v1) {
+    const uint64_t *b = e.blocks + (i >> kBefShift) * 8;
+    const uint32_t t = (uint32_t)(i & (kBefSpan - 1));
+    uint64_t L[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 8; ++j) L[j] = b[j];
+    const uint64_t hdr = L[0];
+    const uint64_t base = hdr & ((1ull << 40) - 1);
+    if (hdr >> 63) { // overflow block: plain values
+        const uint64_t *o = e.ovf + base;
+        v0 = o[t];
+        v1 = o[t + 1];
+        return;
+    }
+    const uint32_t l = (uint32_t)((hdr >> 40) & 63);
+    // ones number t-1 (element t) and t (element t+1) of the unary high part; element 0 is the base
+    uint32_t need = t == 0 ? 0 : t - 1; // index of the first one we need
+    uint32_t p_first = 0, p_second = 0, acc = 0;
+    bool got_first = false, got_second = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 1; j < 8; ++j) {
+        uint64_t word = L[j];
+        uint32_t c = popc64(word);
+        if (!got_first && need < acc + c) {
+            uint32_t bit = select_in_word(word, need - acc);
+            p_first = (uint32_t)(j - 1) * 64 + bit;
+            got_first = true;
+            uint64_t rest = bit == 63 ? 0 : (word & (~0ull << (bit + 1)));
+            if (rest) { p_second = (uint32_t)(j - 1) * 64 + ctz64(rest); got_second = true; }
+        } else if (got_first && !got_second && word) {
+            p_second = (uint32_t)(j - 1) * 64 + ctz64(word);
+            got_second = true;
+        }
+        acc += c;
+    }
+    // low parts from the bit planes
+    uint32_t lo_a = 0, lo_b = 0; // low part of element `need+1` and of the following element
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t pl = 0; pl < kBefMaxL; ++pl) {
+        if (pl < l) {
+            uint64_t plane = L[7 - pl];
+            lo_a |= (uint32_t)((plane >> need) & 1) << pl;
+            lo_b |= (uint32_t)((plane >> ((need + 1) & 63)) & 1) << pl;
+        }
+    }
+    uint64_t r_a = ((uint64_t)(p_first - need) << l) | lo_a;            // element need+1
+    uint64_t r_b = ((uint64_t)(p_second - (need + 1)) << l) | lo_b;     // element need+2
+    if (t == 0) { v0 = base; v1 = base + r_a; }
+    else { v0 = base + r_a; v1 = base + r_b; }
+}
+
 struct IndexView {
     uint32_t k, w;
     uint64_t seed;
@@ -211,8 +284,8 @@ struct IndexView {
     const uint64_t *useq;      // 2-bit packed unitig concatenation (+2 pad words)
     const uint64_t *bv_blocks; // boundary blocks, 8 words per 256 bases
     MphfView mm;               // minimizer -> bucket id
-    EfView buckets;            // bucket id -> [start,end) in pos  (occs_prefix_sum)
-    const uint64_t *pos;       // packed minimizer positions
+    BefView buckets;           // bucket id -> [start,end) in pos  (occs_prefix_sum, partitioned Elias-Fano)
+    const uint64_t *pos;       // packed (minimizer position << 1 | strand class)
     uint32_t pos_width;
     uint32_t has_skew;
     MphfView skew;             // canonical k-mer -> slot in skew_pos
@@ -354,26 +427,24 @@ MZ_HD mz_k2upos lookup_with_minimizer(const IndexView &ix, uint64_t fw, uint64_t
     uint64_t h;
     if (!mphf_lookup(ix.mm, mn.word, h)) return make_none();       // :478-479
     uint64_t ps, pe;
-    ef_get_pair(ix.buckets, h, ps, pe);                            // :482-483
+    bef_get_pair(ix.buckets, h, ps, pe);                           // :482-483
     if (pe - ps > ix.skew_param) return skew_lookup(ix, fw, rc);   // :486-490
     const uint64_t last_km_start = ix.total_len - k;               // :492
     const uint64_t off_a = mn.offset, off_b = k - mn.offset - w;   // :493
     for (uint64_t pi = ps; pi < pe; ++pi) {                        // :494
-        uint64_t mm_pos = read_packed(ix.pos, pi, ix.pos_width);
-        bool va = mm_pos >= off_a && mm_pos - off_a <= last_km_start; // :498
-        bool vb = mm_pos >= off_b && mm_pos - off_b <= last_km_start; // :527
-        uint64_t pa = mm_pos - off_a, pb = mm_pos - off_b;
-        // both candidate reads are issued before either is consumed
-        uint64_t ka = va ? read_kmer(ix.useq, pa, k) : 0, kb = vb ? read_kmer(ix.useq, pb, k) : 0;
-        uint32_t ma = va ? word_equivalency(fw, rc, ka) : MZ_NO_MATCH;
-        uint32_t mb = vb ? word_equivalency(fw, rc, kb) : MZ_NO_MATCH;
-        if (ma != MZ_NO_MATCH) {
-            UnitigSpan s = locate_unitig(ix.bv_blocks, pa);
-            if (pa + k <= s.end) return make_hit(s, pa, ma);       // :509-514
-        }
-        if (mb != MZ_NO_MATCH) {
-            UnitigSpan s = locate_unitig(ix.bv_blocks, pb);
-            if (pb + k <= s.end) return make_hit(s, pb, mb);       // :538-541
+        // Entry = (minimizer position << 1) | class.  Class 0: the occurrence was emitted by a
+        // forward-canonical k-mer, so only candidate A (:498) can be a true occurrence; class 1:
+        // reverse-canonical, only candidate B (:527).  The other candidate of the reference loop
+        // can never verify ("strand class bit"), so skipping it keeps results identical.
+        uint64_t ent = read_packed(ix.pos, pi, ix.pos_width);
+        uint64_t mm_pos = ent >> 1, off = (ent & 1) ? off_b : off_a;
+        if (mm_pos >= off && mm_pos - off <= last_km_start) {
+            uint64_t p = mm_pos - off;
+            uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
+            if (mt != MZ_NO_MATCH) {
+                UnitigSpan s = locate_unitig(ix.bv_blocks, p);
+                if (p + k <= s.end) return make_hit(s, p, mt);     // :509-514, :538-541
+            }
         }
     }
     return make_none();                                            // :553

@@ -83,10 +83,11 @@ __global__ __launch_bounds__(kBlock) void k2u_batch_kernel(IndexView ix, const u
 //       LDS list for the next round (geometric shrink)               dense over pending keys
 //   S2  Elias-Fano get(h), get(h+1) -> bucket range                  dense over queries
 //   S3  bucket entries flattened by an LDS prefix sum: one (query, entry) item per lane
-//       iteration: packed pos -> two candidate k-mers -> verify -> unitig locate + boundary
-//       check; the winner is kept with an LDS atomicMin in bucket order (A before B)
+//       iteration: packed (pos, strand class) -> the one candidate k-mer of that class ->
+//       verify; the first verified entry in bucket order is kept with an LDS atomicMin
 //   S4  heavy buckets: skew MPHF (same level loop) -> packed pos -> verify
-//   S5  results materialised from the winning position and stored as coalesced 16-byte records
+//   S5  unitig locate + boundary check of the winner (exact rescan if it straddles two unitigs),
+//       results stored as coalesced 16-byte records
 // ------------------------------------------------------------------------------------
 constexpr int kQpt = 4;                  // queries per thread
 constexpr int kTileQ = kBlock * kQpt;    // queries per tile
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
             bool heavy = false;
             if (act) {
                 uint64_t ps, pe;
-                ef_get_pair(ix.buckets, S.slot[i], ps, pe);
+                bef_get_pair(ix.buckets, S.slot[i], ps, pe);
                 uint64_t cnt = pe - ps;
                 heavy = cnt > ix.skew_param;                        // sshash.rs:486-490
                 S.slot[i] = ps;
@@ -278,25 +279,18 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
                     if (S.eoff[mid] <= e) lo = mid; else hi = mid;
                 }
                 const uint32_t i = lo, j = e - S.eoff[i];
-                const uint64_t mm_pos = read_packed(ix.pos, S.slot[i] + j, ix.pos_width);   // sshash.rs:495
+                const uint64_t ent = read_packed(ix.pos, S.slot[i] + j, ix.pos_width);     // sshash.rs:495
+                const uint64_t mm_pos = ent >> 1;
                 const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                const uint64_t off_a = S.off[i], off_b = k - off_a - w;                  // :493
-                const bool va = mm_pos >= off_a && mm_pos - off_a <= last_km_start;       // :498
-                const bool vb = mm_pos >= off_b && mm_pos - off_b <= last_km_start;       // :527
-                const uint64_t pa = mm_pos - off_a, pb = mm_pos - off_b;
-                const uint64_t ka = va ? read_kmer(ix.useq, pa, k) : 0, kb = vb ? read_kmer(ix.useq, pb, k) : 0;
-                const uint32_t ma = va ? word_equivalency(fw, rc, ka) : MZ_NO_MATCH;
-                const uint32_t mb = vb ? word_equivalency(fw, rc, kb) : MZ_NO_MATCH;
-                const uint64_t jj = j < 0x3FFFFFFu ? j : 0x3FFFFFFu;
-                if (ma != MZ_NO_MATCH) {
-                    UnitigSpan s = locate_unitig(ix.bv_blocks, pa);
-                    if (pa + k <= s.end)                                                  // :509-514
-                        atomicMin(&S.best[i], ((jj * 2) << (kPosBits + 1)) | ((uint64_t)(ma == MZ_TWIN_MATCH) << kPosBits) | pa);
-                }
-                if (mb != MZ_NO_MATCH) {
-                    UnitigSpan s = locate_unitig(ix.bv_blocks, pb);
-                    if (pb + k <= s.end)                                                  // :538-541
-                        atomicMin(&S.best[i], ((jj * 2 + 1) << (kPosBits + 1)) | ((uint64_t)(mb == MZ_TWIN_MATCH) << kPosBits) | pb);
+                const uint64_t off_a = S.off[i];
+                const uint64_t off = (ent & 1) ? k - off_a - w : off_a;                  // class 1: candidate B (:527), class 0: A (:498)
+                if (mm_pos >= off && mm_pos - off <= last_km_start) {
+                    const uint64_t p = mm_pos - off;
+                    const uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
+                    const uint64_t jj = j < 0x7FFFFFFu ? j : 0x7FFFFFFu;
+                    // optimistic: the unitig-boundary check (:509-514) is done once, in S5
+                    if (mt != MZ_NO_MATCH)
+                        atomicMin(&S.best[i], (jj << (kPosBits + 1)) | ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p);
                 }
             }
         }
@@ -337,7 +331,10 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
             if (act && b != kBestNone) {
                 uint64_t p = b & ((1ull << kPosBits) - 1);
                 UnitigSpan s = locate_unitig(ix.bv_blocks, p);
-                r = make_hit(s, p, ((b >> kPosBits) & 1) ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH);
+                if (p + k <= s.end)
+                    r = make_hit(s, p, ((b >> kPosBits) & 1) ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH);
+                else // first verified candidate straddles two unitigs (sshash.rs:509-514): exact in-order rescan
+                    r = lookup(ix, S.fw[i]);
             }
             if (act) out[base + i] = r;
             tally.add(act && r.match != MZ_NO_MATCH, act && r.match == MZ_NO_MATCH, false);
@@ -613,9 +610,8 @@ int device_upload(const SSHashHost &h, int device, DeviceIndex **out) {
     if ((rc = upload(d, h.us.bv_blocks.data(), h.us.bv_blocks.size(), &v.bv_blocks)) != MZ_OK) return fail(rc);
     if ((rc = upload(d, h.us.starts.data(), h.us.starts.size(), &v.starts)) != MZ_OK) return fail(rc);
     if ((rc = upload_mphf(d, h.mm, &v.mm)) != MZ_OK) return fail(rc);
-    if ((rc = upload(d, h.buckets.high.data(), h.buckets.high.size(), &v.buckets.high)) != MZ_OK) return fail(rc);
-    if ((rc = upload(d, h.buckets.sel.data(), h.buckets.sel.size(), &v.buckets.sel)) != MZ_OK) return fail(rc);
-    if ((rc = upload(d, h.buckets.low.data(), h.buckets.low.size(), &v.buckets.low)) != MZ_OK) return fail(rc);
+    if ((rc = upload(d, h.buckets.blocks.data(), h.buckets.blocks.size(), &v.buckets.blocks)) != MZ_OK) return fail(rc);
+    if ((rc = upload(d, h.buckets.ovf.data(), h.buckets.ovf.size(), &v.buckets.ovf)) != MZ_OK) return fail(rc);
     if ((rc = upload(d, h.pos.w.data(), h.pos.w.size(), &v.pos)) != MZ_OK) return fail(rc);
     if (h.has_skew) {
         if ((rc = upload_mphf(d, h.skew, &v.skew)) != MZ_OK) return fail(rc);

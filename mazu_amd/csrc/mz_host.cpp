@@ -146,6 +146,72 @@ int EFVector::build(const uint64_t *xs, uint64_t n_, uint64_t u_) {
     return MZ_OK;
 }
 
+
+// ------------------------------------------------------------------ partitioned Elias-Fano
+int BlockedEF::build(const uint64_t *xs, uint64_t n_, int n_threads) {
+    if (n_ == 0) {
+        set_error("Elias-Fano: empty sequence (Error::EFEmpty)");
+        return MZ_EEMPTY;
+    }
+    for (uint64_t i = 1; i < n_; ++i)
+        if (xs[i] < xs[i - 1]) {
+            set_error("Elias-Fano: sequence not monotone at %llu (Error::EFNotMonotone)", (unsigned long long)i);
+            return MZ_ENOTMONOTONE;
+        }
+    if (xs[n_ - 1] >= (1ull << 40)) {
+        set_error("Elias-Fano: values above 2^40 unsupported");
+        return MZ_EINVAL;
+    }
+    n = n_;
+    uint64_t nb = ((n - 1) >> kBefShift) + 1;
+    blocks.assign(nb * 8, 0);
+    std::vector<uint8_t> over(nb, 0);
+    uint64_t *B = blocks.data();
+    uint8_t *OV = over.data();
+    parallel_for(n_threads, nb, [=](int, uint64_t bb, uint64_t be) {
+        for (uint64_t j = bb; j < be; ++j) {
+            uint64_t first = j << kBefShift;
+            uint64_t last = std::min<uint64_t>(first + kBefSpan, n - 1); // elements first..last (<= 65)
+            uint64_t base = xs[first], span = xs[last] - base;
+            uint32_t cnt = (uint32_t)(last - first); // elements 1..cnt are encoded
+            uint32_t l = 0;
+            bool fits = false;
+            for (l = span >= kBefSpan ? (uint32_t)msb(span / kBefSpan) : 0; l <= kBefMaxL; ++l) {
+                uint64_t high_bits = (span >> l) + kBefSpan + 1;
+                if (high_bits + 64ull * l <= 448) { fits = true; break; }
+            }
+            uint64_t *W = B + j * 8;
+            if (!fits) { OV[j] = 1; continue; }
+            W[0] = base | ((uint64_t)l << 40);
+            for (uint32_t t = 1; t <= cnt; ++t) {
+                uint64_t r = xs[first + t] - base;
+                uint64_t hb = (r >> l) + (t - 1);
+                W[1 + (hb >> 6)] |= 1ull << (hb & 63);
+                for (uint32_t pl = 0; pl < l; ++pl) W[7 - pl] |= ((r >> pl) & 1) << (t - 1);
+            }
+            // pad the missing elements of a short final block with copies of the last value so that
+            // the unary part always holds 64 ones (selects stay in range)
+            uint64_t rl = xs[last] - base;
+            for (uint32_t t = cnt + 1; t <= kBefSpan; ++t) {
+                uint64_t hb = (rl >> l) + (t - 1);
+                W[1 + (hb >> 6)] |= 1ull << (hb & 63);
+                for (uint32_t pl = 0; pl < l; ++pl) W[7 - pl] |= ((rl >> pl) & 1) << (t - 1);
+            }
+        }
+    });
+    ovf.clear();
+    n_overflow = 0;
+    for (uint64_t j = 0; j < nb; ++j) {
+        if (!over[j]) continue;
+        uint64_t first = j << kBefShift, off = ovf.size();
+        for (uint32_t t = 0; t <= kBefSpan; ++t) ovf.push_back(xs[std::min<uint64_t>(first + t, n - 1)]);
+        blocks[j * 8] = off | (1ull << 63);
+        ++n_overflow;
+    }
+    if (ovf.empty()) ovf.assign(2, 0);
+    return MZ_OK;
+}
+
 // ------------------------------------------------------------------ MPHF
 int Mphf::build(const uint64_t *keys_in, uint64_t n, double gamma, int n_threads) {
     n_keys = n;
@@ -375,7 +441,7 @@ int UnitigSet::from_cf_prefix(const std::string &prefix) {
 
 // ------------------------------------------------------------------ SSHash builder
 struct Occ {
-    uint64_t word, pos;
+    uint64_t word, pos; // pos = (position << 1) | strand class for minimizer occurrences; plain position for skew tuples
 };
 static inline bool occ_less(const Occ &a, const Occ &b) { return a.word != b.word ? a.word < b.word : a.pos < b.pos; }
 
@@ -464,11 +530,11 @@ static void scan_unitig(const uint64_t *useq, uint64_t s, uint64_t e, uint32_t k
         } else if (hr[slot] <= hr[rmin & 63]) rmin = j;
         (void)n_win;
         if (fwk <= rck) {
-            Occ o{wf[fmin & 63], fmin};
+            Occ o{wf[fmin & 63], fmin << 1};
             if (o.word != prev_f.word || o.pos != prev_f.pos) out.push_back(o);
             prev_f = o;
         } else {
-            Occ o{wr[rmin & 63], rmin};
+            Occ o{wr[rmin & 63], (rmin << 1) | 1};
             if (o.word != prev_r.word || o.pos != prev_r.pos) out.push_back(o);
             prev_r = o;
         }
@@ -569,7 +635,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
                 for (uint64_t j = R[i]; j < R[i + 1]; ++j) PV[d++] = O[j].pos;
             }
         });
-        max_pos = us.total_len; // every position < total_len
+        max_pos = us.total_len * 2 + 1; // (position << 1) | class
     }
     // 6. skew index (sshash.rs:221-296): k-mers around every occurrence of a heavy minimizer
     if (skew_param != ~0ull) {
@@ -583,7 +649,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
             for (uint64_t i = b; i < e; ++i) {
                 if (R[i + 1] - R[i] <= sp) continue;
                 for (uint64_t j = R[i]; j < R[i + 1]; ++j) {
-                    uint64_t mp = O[j].pos;
+                    uint64_t mp = O[j].pos >> 1;
                     uint64_t start_pos = mp < (uint64_t)(k - w) ? 0 : mp - (k - w);
                     for (uint64_t off = 0; off < (uint64_t)(k - w + 1); ++off) {
                         uint64_t p = start_pos + off;
@@ -624,7 +690,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
         has_skew = true;
     }
     // 7. finish (sshash.rs:310-329): Elias-Fano the prefix sums, bit-pack the positions
-    rc = buckets.build(psum.data(), n_mm + 1, psum[n_mm]);
+    rc = buckets.build(psum.data(), n_mm + 1, nt);
     if (rc != MZ_OK) return rc;
     pos.assign(posv.data(), n_occ, max_pos, nt);
     build_seconds = now_s() - t0;
@@ -663,7 +729,7 @@ uint64_t SSHashHost::num_bits() const {
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '1'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '2'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>
@@ -699,7 +765,7 @@ int SSHashHost::save(const std::string &path) const {
     uint32_t hs = has_skew ? 1 : 0;
     put(f, hs);
     putv(f, us.useq); putv(f, us.starts); putv(f, us.bv_blocks); put_ef(f, us.accum_lens);
-    put_mphf(f, mm); put_ef(f, buckets); put_pv(f, pos);
+    put_mphf(f, mm); put(f, buckets.n); put(f, buckets.n_overflow); putv(f, buckets.blocks); putv(f, buckets.ovf); put_pv(f, pos);
     if (has_skew) { put_mphf(f, skew); put_pv(f, skew_pos); }
     return f ? MZ_OK : (set_error("short write to %s", path.c_str()), MZ_EIO);
 }
@@ -714,7 +780,7 @@ int SSHashHost::load(const std::string &path) {
     uint32_t hs = 0;
     bool ok = get(f, us.k) && get(f, w) && get(f, seed) && get(f, skew_param) && get(f, us.total_len) && get(f, us.n_unitigs) &&
               get(f, n_minimizers) && get(f, hs) && getv(f, us.useq) && getv(f, us.starts) && getv(f, us.bv_blocks) &&
-              get_ef(f, us.accum_lens) && get_mphf(f, mm) && get_ef(f, buckets) && get_pv(f, pos);
+              get_ef(f, us.accum_lens) && get_mphf(f, mm) && get(f, buckets.n) && get(f, buckets.n_overflow) && getv(f, buckets.blocks) && getv(f, buckets.ovf) && get_pv(f, pos);
     has_skew = hs != 0;
     if (ok && has_skew) ok = get_mphf(f, skew) && get_pv(f, skew_pos);
     if (!ok) {

@@ -38,6 +38,16 @@ struct EFVector {
     uint64_t num_bits() const { return 3 * 64 + n_high_bits + n * l; } // elias_fano.rs:31-33
 };
 
+// Partitioned Elias-Fano (one 64-byte line per 64 elements), see BefView in mz_common.hpp.
+struct BlockedEF {
+    uint64_t n = 0, n_overflow = 0;
+    std::vector<uint64_t> blocks, ovf;
+    int build(const uint64_t *xs, uint64_t n_, int n_threads);
+    BefView view() const { return BefView{blocks.data(), ovf.data(), n}; }
+    void get_pair(uint64_t i, uint64_t &a, uint64_t &b) const { bef_get_pair(view(), i, a, b); }
+    uint64_t num_bits() const { return (blocks.size() + ovf.size()) * 64; }
+};
+
 // Minimal perfect hash in the BBHash/boomphf family (reference uses boomphf::Mphf, gamma 1.7,
 // sshash.rs:177,280) stored as rank-interleaved 64-byte blocks.
 struct Mphf {
@@ -79,7 +89,7 @@ struct SSHashHost {
     uint64_t seed = 0;
     uint64_t skew_param = ~0ull;
     Mphf mm;          // mphf
-    EFVector buckets; // occs_prefix_sum
+    BlockedEF buckets; // occs_prefix_sum
     PackedVec pos;    // pos
     bool has_skew = false;
     Mphf skew;        // skew_index.mphf

@@ -94,10 +94,12 @@ def yeast():
     return k, seqs
 
 
-@pytest.mark.parametrize("w,skew", [(15, M.MZ_NO_SKEW_INDEX), (15, 32), (11, 8), (20, 2), (31, M.MZ_NO_SKEW_INDEX), (1, 64)])
+@pytest.mark.parametrize("w,skew", [(15, M.MZ_NO_SKEW_INDEX), (15, 32), (15, 16), (11, 8), (20, 2), (31, M.MZ_NO_SKEW_INDEX), (1, 64), (4, M.MZ_NO_SKEW_INDEX)])
 def test_yeast_validate_self_and_oracle_parity(yeast, w, skew):  # kphf/mod.rs:147-161
     k, seqs = yeast
     ix, orc, (words, total, starts) = both(seqs, k, w, skew)
+    if (w, skew) == (15, 16):
+        assert ix.n_kmers_in_skew_index() != 0 and ix.n_minimizers() < ix.n_kmers()  # caching.rs:247-248 (see test_boundary)
     rep = ix.validate_self_report()
     assert rep == {"n_kmers": 1071346, "n_fail": 0, "n_duplicate": 0, "first_fail_pos": 2**64 - 1}
     q = H.query_mix(words, starts, k, 300000, seed=w)
