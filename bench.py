@@ -29,6 +29,7 @@ import mazu_amd as M  # noqa: E402
 from mazu_amd import synth  # noqa: E402
 
 B_ALG = 208.0        # algorithmic bytes per k-mer query on the 50/50 mix (table in DESIGN.md)
+B_ALG_OWN = 152.0    # same accounting for this repository's layout
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 DEFAULT_BATCH = {"s-tiny": 200_000, "s-yeast": 10_000_000, "s-eighth": 50_000_000, "s-human": 125_000_000}
@@ -76,10 +77,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the k2u path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    import torch.distributed as dist
+    from mazu_amd import dist as D
+    D.init("nccl", dev)  # nccl == RCCL on ROCm; no-op for a single process
 
     k = 31
     batch = args.batch or DEFAULT_BATCH[args.workload]
@@ -100,10 +100,10 @@ def main():
         if shared:
             ix.save(shared)
     if world > 1:
-        dist.barrier()
+        D.barrier()
         if rank != 0:
             ix = M.SSHash.load(shared)
-        dist.barrier()
+        D.barrier()
         if rank == 0:
             os.unlink(shared)
     t_build = time.time() - t0
@@ -134,8 +134,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
@@ -148,14 +147,9 @@ def main():
         a.record(stream)
         step()
         b.record(stream)
-    if world > 1:  # the path's one exchange step: final hit-count all-reduce over RCCL/xGMI
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    D.allreduce_counts(counts)  # the path's one exchange step: final hit-count all-reduce over RCCL/xGMI
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     n_hit, n_miss, _ = counts.cpu().tolist()
     total_q = batch * n_gpus * args.steps
@@ -183,6 +177,7 @@ def main():
             "hit_fraction": round(n_hit / total_q, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac_own_layout": round(batch * B_ALG_OWN / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                          "kernel": "k2u_batch_kernel(v1)" if os.environ.get("MZ_K2U_KERNEL", "") == "v1" else "k2u_tile_kernel", "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_kmer": B_ALG},
             "build": {"gen_s": round(t_gen, 2), "host_build_s": round(t_build, 2), "upload_s": round(t_upload, 2),

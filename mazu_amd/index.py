@@ -1,0 +1,173 @@
+"""Host-side mirror of mazu's index facade around the K2U path (reference src/index.rs,
+src/index/validate.rs, src/index/caching.rs, src/index/dense_unitig_table.rs): ModIndex.from_parts,
+get_ref_pos, validate_self, as_streaming.  The k2u step goes to the GPU through the K2U object
+it is given (mazu_amd.SSHash); occurrence projection stays on the host (numpy) -- it is the
+"next" row of SURVEY.md 8(f), not part of the accelerated path."""
+import numpy as np
+
+from .kphf import CanonicalKmer, MatchType
+from . import pf1
+
+FORWARD, BACKWARD = 1, 0  # Orientation::to_u8, src/lib.rs:50-64
+
+
+class MappedRefPos:  # src/index.rs:26-47
+    __slots__ = ("ref_id", "pos", "o")
+
+    def __init__(self, ref_id, pos, o):
+        self.ref_id, self.pos, self.o = int(ref_id), int(pos), int(o)
+
+    @classmethod
+    def new_fw(cls, ref_id, pos): return cls(ref_id, pos, FORWARD)
+
+    @classmethod
+    def new_rc(cls, ref_id, pos): return cls(ref_id, pos, BACKWARD)
+
+    def __eq__(self, other): return (self.ref_id, self.pos, self.o) == (other.ref_id, other.pos, other.o)
+    def __repr__(self): return f"MappedRefPos(ref_id={self.ref_id}, pos={self.pos}, o={'fw' if self.o else 'rc'})"
+
+
+class DenseUnitigTable:  # src/index/dense_unitig_table.rs:12-76 (U2Pos)
+    def __init__(self, ctable, contig_offsets, ref_names):
+        self.ctable = np.asarray(ctable, dtype=np.uint64)
+        self.contig_offsets = np.asarray(contig_offsets, dtype=np.uint64)
+        self.ref_names = list(ref_names)
+
+    def encoded_unitig_occs(self, ui):
+        return self.ctable[int(self.contig_offsets[ui]): int(self.contig_offsets[ui + 1])]
+
+    @staticmethod
+    def decode_pf1(words):  # UnitigOcc::decode_pf1, src/index.rs:334-346
+        words = np.asarray(words, dtype=np.uint64)
+        ref_id = words & np.uint64(0xFFFFFFFF)
+        pw = words >> np.uint64(32)
+        return ref_id, pw & np.uint64(0x7FFFFFFF), (pw & np.uint64(0x80000000)) != 0
+
+
+class RefSeqCollection:  # src/refseq.rs:17-20
+    def __init__(self, seq_words, prefix_sum):
+        self.seq_words = seq_words
+        self.prefix_sum = np.asarray(prefix_sum, dtype=np.uint64)
+
+    def has_seq(self): return self.seq_words is not None
+    def n_refs(self): return len(self.prefix_sum) - 1
+    def ref_len(self, r): return int(self.prefix_sum[r + 1] - self.prefix_sum[r])
+
+    def kmer_words(self, r, k):
+        """forward words of every k-mer of reference r (RefSeqSlice::iter_kmers)"""
+        s, n = int(self.prefix_sum[r]), self.ref_len(r) - k + 1
+        if n <= 0:
+            return np.zeros(0, dtype=np.uint64)
+        pos = np.arange(s, s + n, dtype=np.uint64)
+        b = pos * np.uint64(2)
+        wi = (b >> np.uint64(6)).astype(np.int64)
+        sh = b & np.uint64(63)
+        w = np.concatenate([self.seq_words, np.zeros(2, dtype=np.uint64)])
+        x = (w[wi] >> sh) | np.where(sh > 0, w[wi + 1] << ((np.uint64(64) - sh) & np.uint64(63)), np.uint64(0))
+        return x & np.uint64((1 << (2 * k)) - 1)
+
+
+def project_onto_u_occs(k, rec, ref_id, cpos, fwd):
+    """project_onto_u_occ (src/index.rs:184-216), vectorised over the occurrences of one unitig"""
+    upos, ulen = int(rec["pos"]), int(rec["unitig_len"])
+    pos = np.where(fwd, upos + cpos.astype(np.int64), cpos.astype(np.int64) + (ulen - upos) - k)
+    o = FORWARD if int(rec["match"]) == MatchType.IdentityMatch else BACKWARD
+    oo = np.where(fwd, o, 1 - o)
+    return [MappedRefPos(r, p, x) for r, p, x in zip(ref_id.tolist(), pos.tolist(), oo.tolist())]
+
+
+class ModIndex:  # src/index.rs:49-124
+    def __init__(self, base, k2u, u2pos, refs):
+        self.base, self.k2u, self.u2pos, self.refs = base, k2u, u2pos, refs
+
+    @classmethod
+    def from_parts(cls, base, k2u, u2pos, refs):  # src/index.rs:80-87
+        return cls(base, k2u, u2pos, refs)
+
+    def k(self): return self.k2u.k()
+    def as_k2u(self): return self.k2u
+    def as_u2pos(self): return self.u2pos
+    def as_refseqs(self): return self.refs
+    def as_ref(self): return self.k2u.as_ref()
+    def n_unitigs(self): return self.k2u.n_unitigs()
+    def n_kmers(self): return self.k2u.n_kmers()
+
+    def get_ref_pos_eager(self, km):  # src/index.rs:139-142,156-179
+        if len(km) != self.k():
+            raise ValueError(f"Got query k-mer size k={len(km)}, expected k={self.k()}.")  # the reference panics
+        recs, _ = self.k2u.k2u_batch(np.array([km.get_fw_mer()], dtype=np.uint64))
+        rec = recs[0]
+        if int(rec["match"]) == 0:
+            return None
+        ref_id, cpos, fwd = DenseUnitigTable.decode_pf1(self.u2pos.encoded_unitig_occs(int(rec["unitig_id"])))
+        return project_onto_u_occs(self.k(), rec, ref_id, cpos, fwd)
+
+    def _validate_batch(self, fw_words, ref_id, ref_pos, k2u_batch):
+        """every queried k-mer must map back to (ref_id, ref_pos): the assertion loop of
+        Validate::validate_self / validate_ckmers (src/index/validate.rs:24-81), vectorised"""
+        k = self.k()
+        recs, _ = k2u_batch(fw_words)
+        if (recs["match"] == 0).any():
+            i = int(np.nonzero(recs["match"] == 0)[0][0])
+            raise AssertionError(f"No MRPs found for true +ve kmer in ref {ref_id} @ pos {int(ref_pos[i])}")
+        off = self.u2pos.contig_offsets
+        uid = recs["unitig_id"].astype(np.int64)
+        s, e = off[uid].astype(np.int64), off[uid + 1].astype(np.int64)
+        cnt = e - s
+        owner = np.repeat(np.arange(len(recs)), cnt)
+        idx = np.repeat(s, cnt) + (np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+        orid, cpos, fwd = DenseUnitigTable.decode_pf1(self.u2pos.ctable[idx])
+        upos, ulen = recs["pos"].astype(np.int64)[owner], recs["unitig_len"].astype(np.int64)[owner]
+        pos = np.where(fwd, upos + cpos.astype(np.int64), cpos.astype(np.int64) + (ulen - upos) - k)
+        ok = (pos == ref_pos.astype(np.int64)[owner]) & (orid.astype(np.int64) == ref_id)
+        found = np.zeros(len(recs), dtype=bool)
+        np.logical_or.at(found, owner, ok)
+        if not found.all():
+            i = int(np.nonzero(~found)[0][0])
+            raise AssertionError(f"No matching MRP for true +ve kmer in ref {ref_id} @ pos {int(ref_pos[i])}")
+        return len(recs)
+
+    def validate_self(self):  # src/index/validate.rs:24-52
+        assert self.refs.has_seq()
+        n = 0
+        for r in range(self.refs.n_refs()):
+            fw = self.refs.kmer_words(r, self.k())
+            n += self._validate_batch(fw, r, np.arange(len(fw)), self.k2u.k2u_batch)
+        return n
+
+    def as_streaming(self):  # src/index/caching.rs:221-232
+        return StreamingIndex(self)
+
+
+class StreamingIndex:  # src/index/caching.rs:37-41,141-219
+    def __init__(self, index):
+        self.index = index
+        self.k2u = index.k2u
+
+    def k(self): return self.index.k()
+
+    def validate_ckmers(self, ref_id, seq):  # caching.rs:175-200: CanonicalKmerIterator skips non-ACGT windows
+        bases = np.frombuffer(seq.encode() if isinstance(seq, str) else seq, dtype=np.uint8)
+        ro = np.array([0, len(bases)], dtype=np.uint64)
+        recs, _ = self.k2u.k2u_reads(bases, ro, streaming=True)
+        keep = recs["match"] != MatchType.Skipped
+        pos = np.nonzero(keep)[0]
+        idx = self.index
+
+        def batch(_fw):
+            return recs[keep], None
+        return idx._validate_batch(np.zeros(int(keep.sum()), dtype=np.uint64), ref_id, pos, batch)
+
+    def validate_fasta(self, path):  # caching.rs:202-218
+        from .fasta import read_fasta
+        return sum(self.validate_ckmers(ri, seq) for ri, (_, seq) in enumerate(read_fasta(path)))
+
+
+def dense_index_from_pf1(d, k2u_factory):
+    """DenseIndex::deserialize_from_cpp (src/pf1/dense_index.rs:33-97) with the K2U built by
+    `k2u_factory(useq_words, total_len, starts, k)` -- the hook where a GPU SSHash is dropped in."""
+    f = pf1.DenseIndexFiles(d)
+    k2u = k2u_factory(f.useq_words, f.total_len, f.starts, f.k)
+    u2pos = DenseUnitigTable(f.ctable, f.contig_offsets, f.ref_names)
+    refs = RefSeqCollection(f.refseq_words, f.ref_prefix_sum)
+    return ModIndex.from_parts({"index_type": "PF1Dense", "info": f.info}, k2u, u2pos, refs), f

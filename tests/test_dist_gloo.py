@@ -1,0 +1,65 @@
+"""N>1 path on CPU: two gloo ranks each take their contiguous shard of one query batch (and of one
+read set), tally hits on their replica, and the single collective of the path -- the all-reduce of
+the tallies -- must reproduce the single-process totals.  The per-rank lookups are played by the
+oracle here (no GPU in this container); on GPUs the same plumbing wraps mz_sshash_k2u_batch_device
+(bench.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+import helpers as H
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, H.ROOT)
+    sys.path.insert(0, os.path.join(H.ROOT, "tests"))
+    from mazu_amd import dist as D
+    from oracle import oracle as O
+    r, w = D.init("gloo")
+    assert (r, w) == (rank, world)
+    k, seqs = H.load_cf_seqs(os.path.join(H.GOLDEN, "cf", "yeast_chr7", "yeast_chr7"))
+    words, total, starts = H.pack_seqs(seqs)
+    orc = O.OracleSSHash(words, total, starts, k, 15, 16, with_dict=False)  # replica on every rank
+    q = np.load(os.path.join(tmp, "q.npy"))
+    lo, hi = D.shard_bounds(len(q), rank, world)
+    out, n_hit = orc.k2u_batch(q[lo:hi])
+    counts = torch.tensor([n_hit, (hi - lo) - n_hit, 0], dtype=torch.int64)
+    D.allreduce_counts(counts)
+    t = D.max_over_ranks(1.0 + rank)
+    D.barrier()
+    np.save(os.path.join(tmp, f"out{rank}.npy"), out)
+    if rank == 0:
+        np.save(os.path.join(tmp, "counts.npy"), counts.numpy())
+        assert t == float(world)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_sharded_counts_allreduce_world2(tmp_path):
+    from mazu_amd import dist as D
+    from oracle import oracle as O
+    assert [D.shard_bounds(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    assert [D.shard_bounds(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    k, seqs = H.load_cf_seqs(os.path.join(H.GOLDEN, "cf", "yeast_chr7", "yeast_chr7"))
+    words, total, starts = H.pack_seqs(seqs)
+    q = H.query_mix(words, starts, k, 60001, seed=77)
+    np.save(tmp_path / "q.npy", q)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want, n_hit = O.OracleSSHash(words, total, starts, k, 15, 16, with_dict=False).k2u_batch(q)
+    counts = np.load(tmp_path / "counts.npy")
+    assert counts.tolist() == [n_hit, len(q) - n_hit, 0]
+    got = np.concatenate([np.load(tmp_path / "out0.npy"), np.load(tmp_path / "out1.npy")])
+    assert got.tobytes() == want.tobytes()  # shards stay in order: concatenation == unsharded result

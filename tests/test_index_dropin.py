@@ -1,0 +1,115 @@
+"""The drop-in property (reference README.md:17-38; src/pf1/dense_index.rs:213-328): load a
+pufferfish dense index, pull out its UnitigSet, put an SSHash in its place with
+ModIndex::from_parts, and validate_self / as_streaming keep working.
+CPU part = BASELINE config 0 (plumbing, K2U played by the oracle); GPU part = the real drop-in."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+import mazu_amd as M
+from mazu_amd import index as I
+from mazu_amd import pf1
+from oracle import oracle as O
+
+KATS = json.load(open(os.path.join(H.GOLDEN, "reference_kats.json")))
+PF1 = os.path.join(H.GOLDEN, "pf1")
+
+
+class OracleK2U:
+    """TEST-ONLY adapter: lets the CPU oracle play the K2U role in the host mirror (config 0)."""
+
+    def __init__(self, words, total, starts, k, w, skew):
+        self.o = O.OracleSSHash(np.concatenate([words, np.zeros(2, dtype=np.uint64)]), total, starts, k, w, skew, with_dict=False)
+
+    def k(self): return self.o.k()
+    def n_unitigs(self): return self.o.n_unitigs()
+    def n_kmers(self): return self.o.n_kmers()
+    def k2u_batch(self, fw): return self.o.k2u_batch(fw, n_threads=4)
+    def k2u_reads(self, bases, ro, streaming=False): r, _, c = self.o.k2u_reads(bases, ro, streaming); return r, c
+
+
+def gpu_factory(w, skew):
+    def f(words, total, starts, k):
+        return M.SSHash.from_unitig_set(M.UnitigSet.from_packed(words, total, starts, k), w, skew)
+    return f
+
+
+def test_pf1_fixture_decoding():  # dense_index.rs:117-129, cpp.rs:245-271
+    f = pf1.DenseIndexFiles(os.path.join(PF1, "tiny_index"))
+    assert f.n_unitigs == KATS["n_unitigs"]["tiny_index"] and f.k == 3 and f.total_len == 6
+    assert f.pos_width == 3 and pf1.unpack(f.pos_words, 3, f.n_pos).tolist() == [3, 2, 0, 1]
+    f = pf1.DenseIndexFiles(os.path.join(PF1, "yeast_chr01_index"))
+    assert f.n_unitigs == KATS["n_unitigs"]["yeast_chr01_index"] and f.pos_width == 18
+    assert f.total_len == 239228 and int(f.starts[-1]) == 239228
+
+
+@pytest.mark.parametrize("name,w,skew", [("tiny_index", 2, O.NO_SKEW), ("tiny-rc_index", 2, O.NO_SKEW),
+                                         ("tiny-multi-refs/tiny-multi-refs_index", 3, 0), ("small_txome_index", 15, 32),
+                                         ("yeast_chr01_index", 15, 32)])
+def test_config0_plumbing_on_cpu(name, w, skew):  # dense_index.rs:274-328 with the oracle as K2U
+    idx, f = I.dense_index_from_pf1(os.path.join(PF1, name), lambda a, b, c, k: OracleK2U(a, b, c, k, w, skew))
+    n = idx.validate_self()
+    assert n == sum(max(0, idx.refs.ref_len(r) - f.k + 1) for r in range(idx.refs.n_refs()))
+    if name == "yeast_chr01_index":
+        assert n == 230188 and idx.n_unitigs() == 577
+
+
+def test_tiny_k3_known_ref_positions_on_cpu():  # dense_index.rs:168-265
+    idx, f = I.dense_index_from_pf1(os.path.join(PF1, "tiny_index"), lambda a, b, c, k: OracleK2U(a, b, c, k, 2, O.NO_SKEW))
+    kat = KATS["tiny_k3_refpos"]
+    for hit in kat["hits"]:
+        km = M.CanonicalKmer(hit["kmer"])
+        assert idx.get_ref_pos_eager(km) == [I.MappedRefPos.new_fw(hit["ref_id"], hit["pos"])]
+        km.swap()
+        assert idx.get_ref_pos_eager(km) == [I.MappedRefPos.new_rc(hit["ref_id"], hit["pos"])]
+    for miss in kat["misses"]:
+        assert idx.get_ref_pos_eager(M.CanonicalKmer(miss)) is None
+    with pytest.raises(ValueError):  # dense_index.rs:148-163 (#[should_panic])
+        idx.get_ref_pos_eager(M.CanonicalKmer("aaaaaa"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,skew", [("tiny_index", 2, M.MZ_NO_SKEW_INDEX), ("tiny-multi-refs/tiny-multi-refs_index", 3, 0),
+                                         ("small_txome_index", 15, 32), ("yeast_chr01_index", 15, 32), ("yeast_chr01_index", 15, 8)])
+def test_readme_dropin_on_gpu(name, w, skew):  # README.md:17-38, dense_index.rs:314-328
+    idx, f = I.dense_index_from_pf1(os.path.join(PF1, name), gpu_factory(w, skew))
+    idx.as_k2u().validate_self()                      # K2U::validate_self on the device
+    n = idx.validate_self()                           # Validate::validate_self over the stored references
+    if name == "yeast_chr01_index":
+        assert n == 230188
+    # .as_streaming(): walk every stored reference through the reads kernel (caching.rs:175-218)
+    st = idx.as_streaming()
+    for r in range(idx.refs.n_refs()):
+        fw = idx.refs.kmer_words(r, f.k)
+        seq = "".join(H.decode_kmer(int(x), 1) for x in (fw & np.uint64(3))) if len(fw) else ""
+        if len(fw):
+            seq += H.decode_kmer(int(fw[-1]), f.k)[1:]
+            assert st.validate_ckmers(r, seq) == len(fw)
+
+
+@pytest.mark.gpu
+def test_tiny_k3_known_ref_positions_on_gpu():  # dense_index.rs:213-265 (SSHash w=2 dropped into tiny_index)
+    idx, f = I.dense_index_from_pf1(os.path.join(PF1, "tiny_index"), gpu_factory(2, M.MZ_NO_SKEW_INDEX))
+    for hit in KATS["tiny_k3_refpos"]["hits"]:
+        km = M.CanonicalKmer(hit["kmer"])
+        assert idx.get_ref_pos_eager(km) == [I.MappedRefPos.new_fw(hit["ref_id"], hit["pos"])]
+        km.swap()
+        assert idx.get_ref_pos_eager(km) == [I.MappedRefPos.new_rc(hit["ref_id"], hit["pos"])]
+    for miss in KATS["tiny_k3_refpos"]["misses"]:
+        assert idx.get_ref_pos_eager(M.CanonicalKmer(miss)) is None
+
+
+@pytest.mark.gpu
+def test_streaming_validate_fasta_piscem_style():  # caching.rs:238-253 / piscem_index.rs:63-99 on cf fixtures
+    """validate_fasta through .as_streaming(): every ACGT window of the FASTA the unitigs were built
+    from must be found (tiny.fa contains Ns)."""
+    for prefix, w, skew in ((os.path.join(H.GOLDEN, "cf", "tiny", "tiny"), 3, M.MZ_NO_SKEW_INDEX),
+                            (os.path.join(H.GOLDEN, "cf", "yeast_chr7", "yeast_chr7"), 15, 16)):
+        ix = M.SSHash.from_unitig_set(M.UnitigSet.from_cf_prefix(prefix), w, skew)
+        for _, seq in H.read_fasta(prefix + ".fa"):
+            bases = np.frombuffer(seq.encode(), dtype=np.uint8)
+            recs, counts = ix.k2u_reads(bases, np.array([0, len(bases)], dtype=np.uint64), streaming=True)
+            assert counts[1] == 0 and counts[0] + counts[2] == len(recs) and counts[0] > 0
