@@ -39,17 +39,23 @@ def log(msg):
     print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads):
-    """oracle ('port' of sshash.rs) timed on this box's host cores over a bounded sample"""
+def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads, target_s=8.0):
+    """oracle ('port' of sshash.rs) timed on this box's host cores over a bounded sample: a pilot of
+    1 M queries sizes the sample so that the timed region lasts about `target_s` seconds"""
     from oracle import oracle as O
     t0 = time.time()
     orc = O.OracleSSHash(us_host[0], us_host[1], us_host[2], k, w, skew, seed, with_dict=False)
     t_build = time.time() - t0
-    orc.k2u_batch(q_host[:100000], n_threads=n_threads)  # warm
+    n_pilot = min(len(q_host), 1_000_000)
+    orc.k2u_batch(q_host[:n_pilot], n_threads=n_threads)  # warms threads and caches
     t0 = time.time()
-    out, n_hit = orc.k2u_batch(q_host, n_threads=n_threads)
+    orc.k2u_batch(q_host[:n_pilot], n_threads=n_threads)
+    pilot_rate = n_pilot / max(time.time() - t0, 1e-6)
+    n = int(min(len(q_host), max(n_pilot, pilot_rate * target_s)))
+    t0 = time.time()
+    out, n_hit = orc.k2u_batch(q_host[:n], n_threads=n_threads)
     dt = time.time() - t0
-    return orc, out, n_hit, len(q_host) / dt / 1e6, t_build, dt
+    return out, n_hit, n, n / dt / 1e6, t_build, dt
 
 
 def main():
@@ -186,16 +192,15 @@ def main():
         if validate is not None:
             res["validate_self"] = validate
         if n_gpus == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            n_sample = args.cpu_sample or min(batch, 4_000_000)
-            q_host = q[:n_sample].cpu().numpy().view(np.uint64)
-            orc, want, orc_hits, cpu_rate, t_ob, t_q = cpu_baseline((words_h, us["total_len"], starts_h), k, args.w, args.skew,
-                                                                    args.seed, q_host, cores)
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            q_host = q[: (args.cpu_sample or batch)].cpu().numpy().view(np.uint64)
+            want, orc_hits, n_sample, cpu_rate, t_ob, t_q = cpu_baseline((words_h, us["total_len"], starts_h), k, args.w, args.skew,
+                                                                       args.seed, q_host, cores)
             got = out[: 2 * n_sample].cpu().numpy().view(M.K2UPOS_DTYPE)
             same = got.tobytes() == want.tobytes()
             res["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "M k-mers/s", "cores": cores, "kind": "port",
-                                   "sample": f"first {n_sample} queries of the rank-0 batch on the same {args.workload} index "
-                                             f"(oracle build {t_ob:.1f}s, query {t_q:.1f}s)",
+                                   "sample": f"first {n_sample} queries of the rank-0 batch on the same {args.workload} index, "
+                                             f"OpenMP static shards over {cores} threads (oracle build {t_ob:.1f}s, query {t_q:.1f}s)",
                                    "results_identical_to_gpu": same}
             res["gpu_over_cpu"] = round(value / cpu_rate, 1)
             assert same, "GPU results differ from the CPU oracle on the sampled queries"

@@ -275,9 +275,14 @@ static void mphf_build(mphf *m, const uint64_t *keys_in, uint64_t n, double gamm
         bitvec occ, col;
         bv_init(&occ, size);
         bv_init(&col, size);
-        for (uint64_t i = 0; i < remaining; ++i) {
-            uint64_t p = mphf_level_pos(keys[i], m->n_levels, size);
-            if (bv_get(&occ, p)) bv_set(&col, p); else bv_set(&occ, p);
+        {
+            unsigned lvl = m->n_levels;
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)remaining; ++i) {
+                uint64_t p = mphf_level_pos(keys[i], lvl, size), bit = 1ull << (p & 63);
+                uint64_t old = __atomic_fetch_or(&occ.w[p >> 6], bit, __ATOMIC_RELAXED);
+                if (old & bit) __atomic_fetch_or(&col.w[p >> 6], bit, __ATOMIC_RELAXED);
+            }
         }
         for (uint64_t j = 0; j < occ.n_words; ++j) occ.w[j] &= ~col.w[j];
         uint64_t nr = 0;
@@ -395,31 +400,95 @@ orc_index *orc_build(const uint64_t *useq_words, uint64_t total_len, const uint6
 
     /* 1. collect minimizer occurrences, sshash.rs:97-143: per unitig, first the
      *    fw-canonical k-mers then the rc-canonical k-mers, each with its own
-     *    consecutive-duplicate filter; pos = minimizer start on the fw strand. */
-    uint64_t cap = 1024, n_occ = 0;
-    mm_occ *occs = (mm_occ *)malloc(cap * sizeof *occs);
-    for (uint64_t ui = 0; ui < n_unitigs; ++ui) {
-        uint64_t s = starts[ui], e = starts[ui + 1];
-        if (e - s < k) continue;
-        for (int pass = 0; pass < 2; ++pass) {
-            int have_prev = 0; uint64_t prev_w = 0, prev_p = 0;
-            for (uint64_t p = s; p + k <= e; ++p) {
-                uint64_t fw = seq_get_kmer(us->useq, p, k);
+     *    consecutive-duplicate filter; pos = minimizer start on the fw strand.
+     *    Unitigs are split into contiguous chunks over the OpenMP threads and the
+     *    per-chunk lists concatenated in chunk order, so the global insertion
+     *    order is the reference's (unitig order, fw pass before rc pass). */
+    int n_chunks = 1;
+#ifdef _OPENMP
+    n_chunks = omp_get_max_threads();
+#endif
+    if ((uint64_t)n_chunks > n_unitigs) n_chunks = (int)n_unitigs;
+    mm_occ **part = (mm_occ **)calloc((size_t)n_chunks, sizeof *part);
+    uint64_t *part_n = (uint64_t *)calloc((size_t)n_chunks, 8);
+#pragma omp parallel for schedule(static, 1)
+    for (int c = 0; c < n_chunks; ++c) {
+        /* chunk c = unitigs whose start lies in [total_len*c/n, total_len*(c+1)/n) */
+        uint64_t lo_pos = total_len / (uint64_t)n_chunks * (uint64_t)c;
+        uint64_t hi_pos = c + 1 == n_chunks ? total_len : total_len / (uint64_t)n_chunks * (uint64_t)(c + 1);
+        uint64_t a = 0, b = n_unitigs; /* first unitig with start >= lo_pos */
+        while (a < b) { uint64_t m = (a + b) / 2; if (starts[m] < lo_pos) a = m + 1; else b = m; }
+        uint64_t u_lo = a;
+        a = 0; b = n_unitigs;
+        while (a < b) { uint64_t m = (a + b) / 2; if (starts[m] < hi_pos) a = m + 1; else b = m; }
+        uint64_t u_hi = a;
+        uint64_t cap = 1024, n = 0, tcap = 0;
+        mm_occ *occ = (mm_occ *)malloc(cap * sizeof *occ);
+        uint64_t *t_w = NULL, *t_p = NULL; uint8_t *t_f = NULL; /* per-unitig minimizer of every k-mer */
+        for (uint64_t ui = u_lo; ui < u_hi; ++ui) {
+            uint64_t s = starts[ui], e = starts[ui + 1];
+            if (e - s < k) continue;
+            uint64_t nk = e - s - k + 1;
+            if (nk > tcap) {
+                tcap = nk * 2;
+                t_w = (uint64_t *)realloc(t_w, tcap * 8); t_p = (uint64_t *)realloc(t_p, tcap * 8); t_f = (uint8_t *)realloc(t_f, tcap);
+            }
+            for (uint64_t j = 0; j < nk; ++j) {
+                uint64_t fw = seq_get_kmer(us->useq, s + j, k);
                 uint64_t mw; unsigned o; int is_fw;
                 canonical_minimizer(fw, k, w, seed, &mw, &o, &is_fw);
-                if ((pass == 0) != (is_fw != 0)) continue;
-                uint64_t mp = is_fw ? p + o : p + (k - o - w);
-                if (!have_prev || prev_w != mw || prev_p != mp) {
-                    if (n_occ == cap) { cap *= 2; occs = (mm_occ *)realloc(occs, cap * sizeof *occs); }
-                    occs[n_occ].word = mw; occs[n_occ].pos = mp; occs[n_occ].seq = n_occ; ++n_occ;
+                t_w[j] = mw; t_f[j] = (uint8_t)is_fw;
+                t_p[j] = is_fw ? s + j + o : s + j + (k - o - w);
+            }
+            for (int pass = 0; pass < 2; ++pass) {
+                int have_prev = 0; uint64_t prev_w = 0, prev_p = 0;
+                for (uint64_t j = 0; j < nk; ++j) {
+                    if ((pass == 0) != (t_f[j] != 0)) continue;
+                    if (!have_prev || prev_w != t_w[j] || prev_p != t_p[j]) {
+                        if (n == cap) { cap *= 2; occ = (mm_occ *)realloc(occ, cap * sizeof *occ); }
+                        occ[n].word = t_w[j]; occ[n].pos = t_p[j]; occ[n].seq = 0; ++n;
+                    }
+                    have_prev = 1; prev_w = t_w[j]; prev_p = t_p[j];
                 }
-                have_prev = 1; prev_w = mw; prev_p = mp;
             }
         }
+        free(t_w); free(t_p); free(t_f);
+        part[c] = occ; part_n[c] = n;
     }
-    if (n_occ == 0) { free(occs); orc_free(ix); return NULL; }
-    /* 2. stable sort by w-mer word, run-length -> mm_set / mm_occs, sshash.rs:150-172 */
-    qsort(occs, n_occ, sizeof *occs, cmp_mm_occ);
+    uint64_t n_occ = 0;
+    for (int c = 0; c < n_chunks; ++c) n_occ += part_n[c];
+    if (n_occ == 0) { for (int c = 0; c < n_chunks; ++c) free(part[c]); free(part); free(part_n); orc_free(ix); return NULL; }
+    mm_occ *occs = (mm_occ *)malloc(n_occ * sizeof *occs);
+    {
+        uint64_t off = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            memcpy(occs + off, part[c], part_n[c] * sizeof *occs);
+            off += part_n[c];
+            free(part[c]);
+        }
+        free(part); free(part_n);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)n_occ; ++i) occs[i].seq = (uint64_t)i;
+    }
+    /* 2. stable sort by w-mer word (par_sort_by_key, sshash.rs:150): partition on the top bits of
+     *    the word, then sort every partition by (word, insertion index) */
+    {
+        unsigned wb = 2 * w, B = wb < 10 ? wb : 10, shift = wb - B;
+        uint64_t nbk = 1ull << B;
+        uint64_t *bstart = (uint64_t *)calloc(nbk + 1, 8);
+        for (uint64_t i = 0; i < n_occ; ++i) bstart[(occs[i].word >> shift) + 1]++;
+        for (uint64_t b = 0; b < nbk; ++b) bstart[b + 1] += bstart[b];
+        uint64_t *cur = (uint64_t *)malloc(nbk * 8);
+        memcpy(cur, bstart, nbk * 8);
+        mm_occ *tmp = (mm_occ *)malloc(n_occ * sizeof *tmp);
+        for (uint64_t i = 0; i < n_occ; ++i) tmp[cur[occs[i].word >> shift]++] = occs[i];
+        free(cur); free(occs); occs = tmp;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)nbk; ++b)
+            qsort(occs + bstart[b], bstart[b + 1] - bstart[b], sizeof *occs, cmp_mm_occ);
+        free(bstart);
+    }
+    /* run-length -> mm_set / mm_occs, sshash.rs:153-172 */
     uint64_t n_mm = 0;
     for (uint64_t i = 0; i < n_occ; ++i) if (i == 0 || occs[i].word != occs[i - 1].word) ++n_mm;
     uint64_t *mm_set = (uint64_t *)malloc(n_mm * 8), *mm_cnt = (uint64_t *)calloc(n_mm, 8);
@@ -437,41 +506,75 @@ orc_index *orc_build(const uint64_t *useq_words, uint64_t total_len, const uint6
     mphf_build(&ix->mm_mphf, mm_set, n_mm, 1.7);
     /* 4. bucket sizes by hash value -> prefix sums, sshash.rs:181-189 (util.rs:26-38) */
     uint64_t *n_by_h = (uint64_t *)calloc(n_mm, 8), *psum = (uint64_t *)malloc((n_mm + 1) * 8);
-    for (uint64_t i = 0; i < n_mm; ++i) {
+    uint64_t *slot = (uint64_t *)malloc(n_mm * 8);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n_mm; ++i) {
         uint64_t h = 0; mphf_try_hash(&ix->mm_mphf, mm_set[i], &h);
+        slot[i] = h;
         n_by_h[h] = mm_cnt[i];
     }
     { uint64_t acc = 0; for (uint64_t i = 0; i < n_mm; ++i) { psum[i] = acc; acc += n_by_h[i]; } psum[n_mm] = acc; }
     /* 5. scatter positions, sshash.rs:196-219 */
     uint64_t *pos = (uint64_t *)malloc(n_occ * 8), max_pos = 0;
-    for (uint64_t i = 0; i < n_mm; ++i) {
-        uint64_t h = 0; mphf_try_hash(&ix->mm_mphf, mm_set[i], &h);
-        uint64_t sh = psum[h];
-        for (uint64_t j = ranges[i]; j < ranges[i + 1]; ++j) {
-            pos[sh + (j - ranges[i])] = occs[j].pos;
-            if (occs[j].pos > max_pos) max_pos = occs[j].pos;
-        }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n_mm; ++i) {
+        uint64_t sh = psum[slot[i]];
+        for (uint64_t j = ranges[i]; j < ranges[i + 1]; ++j) pos[sh + (j - ranges[i])] = occs[j].pos;
     }
+    for (uint64_t i = 0; i < n_occ; ++i) if (pos[i] > max_pos) max_pos = pos[i];
+    free(slot);
     /* 6. skew index, sshash.rs:222-296 */
     if (skew_param != UINT64_MAX) {
-        uint64_t scap = 1024, sn = 0;
-        wp_pair *tup = (wp_pair *)malloc(scap * sizeof *tup);
-        for (uint64_t i = 0; i < n_mm; ++i) {
-            if (mm_cnt[i] <= skew_param) continue;
-            for (uint64_t j = ranges[i]; j < ranges[i + 1]; ++j) {
-                uint64_t mp = occs[j].pos;
-                uint64_t start_pos = mp < (uint64_t)(k - w) ? 0 : mp - (k - w);
-                for (uint64_t off = 0; off < (uint64_t)(k - w + 1); ++off) {
-                    uint64_t p = start_pos + off;
-                    if (us_is_valid_useq_pos(us, p)) {
-                        uint64_t x = seq_get_kmer(us->useq, p, k), r = kmer_rc(x, k);
-                        if (sn == scap) { scap *= 2; tup = (wp_pair *)realloc(tup, scap * sizeof *tup); }
-                        tup[sn].word = x < r ? x : r; tup[sn].pos = p; ++sn;
+        int nt = 1;
+#ifdef _OPENMP
+        nt = omp_get_max_threads();
+#endif
+        wp_pair **sp = (wp_pair **)calloc((size_t)nt, sizeof *sp);
+        uint64_t *sp_n = (uint64_t *)calloc((size_t)nt, 8), *sp_cap = (uint64_t *)calloc((size_t)nt, 8);
+#pragma omp parallel
+        {
+            int t = 0;
+#ifdef _OPENMP
+            t = omp_get_thread_num();
+#endif
+#pragma omp for schedule(static)
+            for (int64_t i = 0; i < (int64_t)n_mm; ++i) {
+                if (mm_cnt[i] <= skew_param) continue;
+                for (uint64_t j = ranges[i]; j < ranges[i + 1]; ++j) {
+                    uint64_t mp = occs[j].pos;
+                    uint64_t start_pos = mp < (uint64_t)(k - w) ? 0 : mp - (k - w);
+                    for (uint64_t off = 0; off < (uint64_t)(k - w + 1); ++off) {
+                        uint64_t p = start_pos + off;
+                        if (us_is_valid_useq_pos(us, p)) {
+                            uint64_t x = seq_get_kmer(us->useq, p, k), r = kmer_rc(x, k);
+                            if (sp_n[t] == sp_cap[t]) { sp_cap[t] = sp_cap[t] ? sp_cap[t] * 2 : 1024; sp[t] = (wp_pair *)realloc(sp[t], sp_cap[t] * sizeof(wp_pair)); }
+                            sp[t][sp_n[t]].word = x < r ? x : r; sp[t][sp_n[t]].pos = p; ++sp_n[t];
+                        }
                     }
                 }
             }
         }
-        qsort(tup, sn, sizeof *tup, cmp_wp);
+        uint64_t sn = 0;
+        for (int t = 0; t < nt; ++t) sn += sp_n[t];
+        wp_pair *tup = (wp_pair *)malloc((sn ? sn : 1) * sizeof *tup);
+        { uint64_t off = 0; for (int t = 0; t < nt; ++t) { if (sp_n[t]) memcpy(tup + off, sp[t], sp_n[t] * sizeof *tup); off += sp_n[t]; free(sp[t]); } }
+        free(sp); free(sp_n); free(sp_cap);
+        { /* sort by (word, pos): partition on the top bits of the 2k-bit word, sort partitions */
+            unsigned wb = 2 * k, B = wb < 10 ? wb : 10, shift = wb - B;
+            uint64_t nbk = 1ull << B;
+            uint64_t *bstart = (uint64_t *)calloc(nbk + 1, 8);
+            for (uint64_t i = 0; i < sn; ++i) bstart[(tup[i].word >> shift) + 1]++;
+            for (uint64_t b = 0; b < nbk; ++b) bstart[b + 1] += bstart[b];
+            uint64_t *cur = (uint64_t *)malloc(nbk * 8);
+            memcpy(cur, bstart, nbk * 8);
+            wp_pair *tmp = (wp_pair *)malloc((sn ? sn : 1) * sizeof *tmp);
+            for (uint64_t i = 0; i < sn; ++i) tmp[cur[tup[i].word >> shift]++] = tup[i];
+            free(cur); free(tup); tup = tmp;
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int64_t b = 0; b < (int64_t)nbk; ++b)
+                qsort(tup + bstart[b], bstart[b + 1] - bstart[b], sizeof *tup, cmp_wp);
+            free(bstart);
+        }
         uint64_t un = 0;
         for (uint64_t i = 0; i < sn; ++i) if (i == 0 || tup[i].word != tup[un - 1].word) tup[un++] = tup[i];
         uint64_t *km_set = (uint64_t *)malloc((un ? un : 1) * 8), smax = 0;
