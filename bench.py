@@ -42,6 +42,7 @@ def log(msg):
 def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads, target_s=8.0):
     """oracle ('port' of sshash.rs) timed on this box's host cores over a bounded sample: a pilot of
     1 M queries sizes the sample so that the timed region lasts about `target_s` seconds"""
+    os.environ["OMP_NUM_THREADS"] = str(n_threads)  # before libgomp initialises inside liboracle.so
     from oracle import oracle as O
     t0 = time.time()
     orc = O.OracleSSHash(us_host[0], us_host[1], us_host[2], k, w, skew, seed, with_dict=False)
@@ -192,7 +193,7 @@ def main():
         if validate is not None:
             res["validate_self"] = validate
         if n_gpus == 1 and not args.no_cpu_baseline:
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = M.lib.mz_host_threads()  # hardware threads capped by the cgroup CPU quota of this box
             q_host = q[: (args.cpu_sample or batch)].cpu().numpy().view(np.uint64)
             want, orc_hits, n_sample, cpu_rate, t_ob, t_q = cpu_baseline((words_h, us["total_len"], starts_h), k, args.w, args.skew,
                                                                        args.seed, q_host, cores)

@@ -84,6 +84,9 @@ const char *mz_last_error(void);
 uint32_t mz_abi_version(void);
 /* number of visible HIP devices (0 when there is none; never an error) */
 int mz_device_count(void);
+/* host threads the builder uses by default: hardware concurrency capped by the cgroup CPU quota
+ * (override with MZ_NUM_THREADS) */
+int mz_host_threads(void);
 
 /* ---------------------------------------------------------------- UnitigSet */
 /* UnitigSet::from_seqs(&[String], k), unitig_set.rs:74-106.  ACGT/acgt only (MZ_EINVAL otherwise). */

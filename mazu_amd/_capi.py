@@ -46,6 +46,7 @@ def _load():
         "mz_last_error": (C.c_char_p, []),
         "mz_abi_version": (u32, []),
         "mz_device_count": (i, []),
+        "mz_host_threads": (i, []),
         "mz_unitig_set_from_seqs": (i, [p, u64, u32, p]),
         "mz_unitig_set_from_cf_prefix": (i, [C.c_char_p, p]),
         "mz_unitig_set_from_packed": (i, [p, u64, p, u64, u32, p]),

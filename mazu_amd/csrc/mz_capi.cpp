@@ -47,6 +47,7 @@ extern "C" {
 const char *mz_last_error(void) { return last_error(); }
 uint32_t mz_abi_version(void) { return 1; }
 int mz_device_count(void) { return device_count(); }
+int mz_host_threads(void) { return hw_threads(); }
 
 // ---------------------------------------------------------------- UnitigSet
 #define NEW_US(call)                                  \

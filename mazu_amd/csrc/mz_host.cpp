@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <functional>
@@ -27,9 +28,26 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
+// usable host threads: hardware concurrency capped by the cgroup CPU quota (a container may see
+// 256 CPUs but own 16 of them; oversubscribing the quota only adds throttling)
 int hw_threads() {
     unsigned n = std::thread::hardware_concurrency();
-    return n ? (int)n : 1;
+    if (n == 0) n = 1;
+    double quota = 0;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
+        char q[64];
+        long long period = 0;
+        if (std::fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) quota = std::atof(q) / (double)period;
+        std::fclose(f);
+    } else {
+        long long q = -1, period = 0;
+        if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lld", &q) != 1) q = -1; std::fclose(g); }
+        if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lld", &period) != 1) period = 0; std::fclose(g); }
+        if (q > 0 && period > 0) quota = (double)q / (double)period;
+    }
+    if (quota >= 1.0 && quota < (double)n) n = (unsigned)(quota + 0.5);
+    if (const char *e = std::getenv("MZ_NUM_THREADS")) { int v = std::atoi(e); if (v > 0) n = (unsigned)v; }
+    return (int)n;
 }
 
 // run fn(tid, begin, end) over [0, n) split into contiguous shards
