@@ -285,7 +285,7 @@ struct IndexView {
     const uint64_t *bv_blocks; // boundary blocks, 8 words per 256 bases
     MphfView mm;               // minimizer -> bucket id
     BefView buckets;           // bucket id -> [start,end) in pos  (occs_prefix_sum, partitioned Elias-Fano)
-    const uint64_t *pos;       // packed (minimizer position << 1 | strand class)
+    const uint64_t *pos;       // packed entries: (minimizer position << 17) | (strand class << 16) | flank16
     uint32_t pos_width;
     uint32_t has_skew;
     MphfView skew;             // canonical k-mer -> slot in skew_pos
@@ -395,6 +395,38 @@ MZ_HD UnitigSpan locate_unitig(const uint64_t *bv_blocks, uint64_t pos) {
     return s;
 }
 
+
+// ---- `pos` entry: (minimizer position << 17) | (strand class << 16) | flank16 ---------------------
+// flank16 = the 4 bases left of the minimizer occurrence (low byte; base pos-4 in the low bits) and
+// the 4 bases right of it (high byte) on the forward strand of the unitig concatenation.  A query
+// whose k-mer really sits on this occurrence must agree with those bases wherever its k-mer covers
+// them, so almost every foreign entry of a bucket is rejected WITHOUT touching the packed sequence
+// (at least 4 flank bases are always covered: min(4,off) + min(4,k-w-off) >= 4 when k-w >= 4).
+// Entries that pass are verified against the 2-bit sequence exactly as in sshash.rs:500-504.
+constexpr uint32_t kFlankBases = 4, kEntryFlankBits = 4 * kFlankBases, kEntryShift = kEntryFlankBits + 1;
+MZ_HD uint64_t make_entry(uint64_t pos, uint32_t cls, uint32_t flank16) { return (pos << kEntryShift) | ((uint64_t)cls << kEntryFlankBits) | flank16; }
+MZ_HD uint32_t flank_of(const uint64_t *useq, uint64_t total_len, uint64_t pos, uint32_t w) {
+    uint32_t f = 0;
+    for (uint32_t j = 0; j < kFlankBases; ++j) {
+        uint64_t pl = pos + j - kFlankBases, pr = pos + w + j; // pl wraps for pos < 4: treated as absent
+        uint32_t bl = (pos + j >= kFlankBases && pl < total_len) ? (uint32_t)((useq[pl >> 5] >> (2 * (pl & 31))) & 3) : 0;
+        uint32_t br = pr < total_len ? (uint32_t)((useq[pr >> 5] >> (2 * (pr & 31))) & 3) : 0;
+        f |= bl << (2 * j);
+        f |= br << (2 * (kFlankBases + j));
+    }
+    return f;
+}
+// does the expected strand word X (minimizer at offset `off` inside it) agree with the entry's flanks?
+MZ_HD bool flank_ok(uint64_t X, uint32_t off, uint32_t k, uint32_t w, uint32_t flank16) {
+    uint32_t nl = off < kFlankBases ? off : kFlankBases;
+    uint32_t room = k - w - off, nr = room < kFlankBases ? room : kFlankBases;
+    uint32_t ql = (uint32_t)(X >> (2 * (off - nl))) & ((1u << (2 * nl)) - 1);
+    uint32_t el = ((flank16 & 0xFFu) >> (2 * (kFlankBases - nl))) & ((1u << (2 * nl)) - 1);
+    uint32_t qr = nr ? (uint32_t)(X >> (2 * (off + w))) & ((1u << (2 * nr)) - 1) : 0;
+    uint32_t er = (flank16 >> (2 * kFlankBases)) & ((1u << (2 * nr)) - 1);
+    return ql == el && qr == er;
+}
+
 // ---- the k2u lookup chain (reference src/kphf/sshash.rs:471-554) ------------------------
 // Compiled for the device by mz_device.hip (the product path).  tests/cpp/host_check.cpp also
 // compiles it for the host to debug the builder without a GPU; libmazu_amd.so exports no host
@@ -437,7 +469,11 @@ MZ_HD mz_k2upos lookup_with_minimizer(const IndexView &ix, uint64_t fw, uint64_t
         // reverse-canonical, only candidate B (:527).  The other candidate of the reference loop
         // can never verify ("strand class bit"), so skipping it keeps results identical.
         uint64_t ent = read_packed(ix.pos, pi, ix.pos_width);
-        uint64_t mm_pos = ent >> 1, off = (ent & 1) ? off_b : off_a;
+        const bool cls = (ent >> kEntryFlankBits) & 1;
+        uint64_t mm_pos = ent >> kEntryShift, off = cls ? off_b : off_a;
+        // expected word on the unitig strand: g* for class 0, its reverse complement for class 1
+        const uint64_t g = fw <= rc ? fw : rc, X = cls ? (fw <= rc ? rc : fw) : g;
+        if (!flank_ok(X, (uint32_t)off, k, w, (uint32_t)(ent & 0xFFFFu))) continue;
         if (mm_pos >= off && mm_pos - off <= last_km_start) {
             uint64_t p = mm_pos - off;
             uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));

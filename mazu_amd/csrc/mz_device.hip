@@ -92,13 +92,15 @@ __global__ __launch_bounds__(kBlock) void k2u_batch_kernel(IndexView ix, const u
 constexpr int kQpt = 4;                  // queries per thread
 constexpr int kTileQ = kBlock * kQpt;    // queries per tile
 constexpr unsigned long long kBestNone = ~0ull;
-constexpr uint32_t kPosBits = 36, kNMiss = 0xFFFFFFFFu, kNSkew = 0xFFFFFFFEu;
+constexpr uint32_t kPosBits = 36;
+// S.n[i]: bucket size (< kNSkew), or one of the markers below (kNIdle: no query in this slot)
+constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu;
 
 struct TileLds {
     uint64_t fw[kTileQ];               // forward word of the query
     uint64_t slot[kTileQ];             // minimizer word -> bucket id h -> bucket start (skew: canonical word -> slot)
     unsigned long long best[kTileQ];   // (bucket order key << 37) | (twin << 36) | global k-mer position
-    uint32_t n[kTileQ];                // bucket size, kNSkew, or kNMiss
+    uint32_t n[kTileQ];                // bucket size, kNSkew, kNIdle or kNMiss
     uint32_t eoff[kTileQ + 1];         // exclusive prefix sum of bucket sizes
     uint16_t list_a[kTileQ], list_b[kTileQ];
     uint8_t off[kTileQ];               // minimizer offset inside g*
@@ -142,12 +144,12 @@ __device__ __forceinline__ bool mphf_eval(const MphfProbe &p, uint64_t &idx) {
 
 // S1 / S4: resolve slot[i] (key) -> MPHF index for the items of list_a[0..cnt_a); items that fall
 // through every level get n[i] = kNMiss.  `dense_first` == all kTileQ items (level 0, no list).
-__device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool dense_first, uint32_t n_valid) {
+__device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool dense_first) {
     const uint32_t t = threadIdx.x;
     uint32_t lv = 0;
     if (dense_first) {
         if (m.n_levels == 0) {
-            for (int q = 0; q < kQpt; ++q) { uint32_t i = q * kBlock + t; if (i < n_valid) S.n[i] = kNMiss; }
+            for (int q = 0; q < kQpt; ++q) { uint32_t i = q * kBlock + t; if (S.n[i] < kNIdle) S.n[i] = kNMiss; }
             return;
         }
         const MphfLevel L = m.levels[0];
@@ -155,15 +157,15 @@ __device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool de
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * kBlock + t;
-            pr[q] = mphf_issue(m, L, i < n_valid ? S.slot[i] : 0);
+            pr[q] = mphf_issue(m, L, S.slot[i]);
         }
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * kBlock + t;
             uint64_t idx;
-            bool hit = mphf_eval(pr[q], idx);
-            if (hit && i < n_valid) S.slot[i] = idx;
-            wave_push(S.list_a, &S.cnt_a, !hit && i < n_valid, i);
+            bool hit = mphf_eval(pr[q], idx), act = S.n[i] < kNIdle;
+            if (hit && act) S.slot[i] = idx;
+            wave_push(S.list_a, &S.cnt_a, !hit && act, i);
         }
         lv = 1;
     }
@@ -200,6 +202,133 @@ __device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool de
     __syncthreads();
 }
 
+// ---- tile producer / consumer API ------------------------------------------------------
+// A kernel fills the tile with tile_set_query() (S0), calls tile_resolve() (S1-S4) from uniform
+// control flow, then reads each item's answer with tile_result() (S5).
+__device__ __forceinline__ void tile_begin(TileLds &S) {
+    if (threadIdx.x == 0) { S.cnt_a = 0; S.cnt_b = 0; S.cnt_skew = 0; }
+}
+__device__ __forceinline__ void tile_set_query(TileLds &S, uint32_t i, uint64_t fw, Minimizer mn, bool valid) {
+    S.fw[i] = fw;
+    S.slot[i] = mn.word;
+    S.off[i] = (uint8_t)mn.offset;
+    S.best[i] = kBestNone;
+    S.n[i] = valid ? 0u : kNIdle;
+}
+
+__device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
+    const uint32_t t = threadIdx.x, k = ix.k, w = ix.w;
+    __syncthreads();
+    // ---- S1: minimizer MPHF
+    tile_mphf(S, ix.mm, true);
+    // ---- S2: bucket range from the partitioned Elias-Fano prefix sums
+#pragma unroll
+    for (int q = 0; q < kQpt; ++q) {
+        uint32_t i = q * kBlock + t;
+        bool act = S.n[i] < kNIdle;
+        bool heavy = false;
+        if (act) {
+            uint64_t ps, pe;
+            bef_get_pair(ix.buckets, S.slot[i], ps, pe);
+            uint64_t cnt = pe - ps;
+            heavy = cnt > ix.skew_param;                        // sshash.rs:486-490
+            S.slot[i] = ps;
+            S.n[i] = heavy ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
+        }
+        wave_push(S.list_b, &S.cnt_skew, heavy, i);
+    }
+    __syncthreads();
+    // ---- S3: flatten bucket entries (exclusive scan of n over the tile, blocked by thread)
+    {
+        uint32_t v[kQpt], sum = 0;
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t nn = S.n[t * kQpt + q];
+            v[q] = sum;
+            sum += (nn >= kNSkew) ? 0u : nn;
+        }
+        uint32_t incl = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(incl, d);
+            if ((int)(t & 63) >= d) incl += o;
+        }
+        if ((t & 63) == 63) S.wave_tot[t >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t wv = 0; wv < (t >> 6); ++wv) wbase += S.wave_tot[wv];
+        uint32_t excl = wbase + incl - sum;
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) S.eoff[t * kQpt + q] = excl + v[q];
+        if (t == kBlock - 1) S.eoff[kTileQ] = excl + sum;
+    }
+    __syncthreads();
+    {
+        const uint32_t E = S.eoff[kTileQ];
+        const uint64_t last_km_start = ix.total_len - k;
+        for (uint32_t e = t; e < E; e += kBlock) {
+            uint32_t lo = 0, hi = kTileQ; // owner item: largest i with eoff[i] <= e
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (S.eoff[mid] <= e) lo = mid; else hi = mid;
+            }
+            const uint32_t i = lo, j = e - S.eoff[i];
+            const uint64_t ent = read_packed(ix.pos, S.slot[i] + j, ix.pos_width);     // sshash.rs:495
+            const bool cls = (ent >> kEntryFlankBits) & 1;
+            const uint64_t mm_pos = ent >> kEntryShift;
+            const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+            const uint64_t off_a = S.off[i];
+            const uint64_t off = cls ? k - off_a - w : off_a;                        // class 1: candidate B (:527), class 0: A (:498)
+            const uint64_t X = cls ? (fw <= rc ? rc : fw) : (fw <= rc ? fw : rc);     // expected word on the unitig strand
+            // flank filter: foreign entries of the bucket are dropped without a sequence gather
+            if (flank_ok(X, (uint32_t)off, k, w, (uint32_t)(ent & 0xFFFFu)) && mm_pos >= off && mm_pos - off <= last_km_start) {
+                const uint64_t p = mm_pos - off;
+                const uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
+                const uint64_t jj = j < 0x7FFFFFFu ? j : 0x7FFFFFFu;
+                // optimistic: the unitig-boundary check (:509-514) is done once, in tile_result
+                if (mt != MZ_NO_MATCH)
+                    atomicMin(&S.best[i], (jj << (kPosBits + 1)) | ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- S4: heavy buckets go through the skew index (sshash.rs:415-433)
+    if (S.cnt_skew != 0) { // uniform
+        const uint32_t ns = S.cnt_skew;
+        __syncthreads();
+        if (ix.has_skew) {
+            for (uint32_t j = t; j < ns; j += kBlock) {
+                uint32_t i = S.list_b[j];
+                uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+                S.slot[i] = fw < rc ? fw : rc;
+                S.list_a[j] = (uint16_t)i;
+                S.eoff[j] = i; // eoff is free now: remember the heavy items across the level loop
+            }
+            if (t == 0) { S.cnt_a = ns; S.cnt_b = 0; }
+            __syncthreads();
+            tile_mphf(S, ix.skew, false);
+            for (uint32_t j = t; j < ns; j += kBlock) {
+                uint32_t i = S.eoff[j];
+                if (S.n[i] == kNMiss) continue;
+                uint64_t p = read_packed(ix.skew_pos, S.slot[i], ix.skew_pos_width);
+                uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+                uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
+                if (mt != MZ_NO_MATCH) S.best[i] = ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// S5: answer of item i (any thread may ask for any item after tile_resolve)
+__device__ __forceinline__ mz_k2upos tile_result(const TileLds &S, const IndexView &ix, uint32_t i) {
+    unsigned long long b = S.best[i];
+    if (b == kBestNone) return make_none();
+    uint64_t p = b & ((1ull << kPosBits) - 1);
+    UnitigSpan s = locate_unitig(ix.bv_blocks, p);
+    if (p + ix.k <= s.end) return make_hit(s, p, ((b >> kPosBits) & 1) ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH);
+    return lookup(ix, S.fw[i]); // first verified candidate straddles two unitigs (sshash.rs:509-514): exact in-order rescan
+}
+
 __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
                                                           mz_k2upos *__restrict__ out, mz_counts *counts) {
     __shared__ TileLds S;
@@ -210,132 +339,22 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t base = tile * kTileQ;
         const uint32_t n_valid = (uint32_t)(n - base < (uint64_t)kTileQ ? n - base : (uint64_t)kTileQ);
-        if (t == 0) { S.cnt_a = 0; S.cnt_b = 0; S.cnt_skew = 0; }
+        tile_begin(S);
         // ---- S0: canonical encode + minimizer
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * kBlock + t;
             uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
             uint64_t rc = kmer_rc(fw, k);
-            Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
-            S.fw[i] = fw;
-            S.slot[i] = mn.word;
-            S.off[i] = (uint8_t)mn.offset;
-            S.best[i] = kBestNone;
-            S.n[i] = 0;
+            tile_set_query(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
         }
-        __syncthreads();
-        // ---- S1: minimizer MPHF
-        tile_mphf(S, ix.mm, true, n_valid);
-        // ---- S2: bucket range from the Elias-Fano prefix sums
-#pragma unroll
-        for (int q = 0; q < kQpt; ++q) {
-            uint32_t i = q * kBlock + t;
-            bool act = i < n_valid && S.n[i] != kNMiss;
-            bool heavy = false;
-            if (act) {
-                uint64_t ps, pe;
-                bef_get_pair(ix.buckets, S.slot[i], ps, pe);
-                uint64_t cnt = pe - ps;
-                heavy = cnt > ix.skew_param;                        // sshash.rs:486-490
-                S.slot[i] = ps;
-                S.n[i] = heavy ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
-            }
-            wave_push(S.list_b, &S.cnt_skew, heavy, i);
-        }
-        __syncthreads();
-        // ---- S3: flatten bucket entries (exclusive scan of n over the tile, blocked by thread)
-        {
-            uint32_t v[kQpt], sum = 0;
-#pragma unroll
-            for (int q = 0; q < kQpt; ++q) {
-                uint32_t nn = S.n[t * kQpt + q];
-                v[q] = sum;
-                sum += (nn >= kNSkew) ? 0u : nn;
-            }
-            uint32_t incl = sum;
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t o = __shfl_up(incl, d);
-                if ((int)(t & 63) >= d) incl += o;
-            }
-            if ((t & 63) == 63) S.wave_tot[t >> 6] = incl;
-            __syncthreads();
-            uint32_t wbase = 0;
-            for (uint32_t wv = 0; wv < (t >> 6); ++wv) wbase += S.wave_tot[wv];
-            uint32_t excl = wbase + incl - sum;
-#pragma unroll
-            for (int q = 0; q < kQpt; ++q) S.eoff[t * kQpt + q] = excl + v[q];
-            if (t == kBlock - 1) S.eoff[kTileQ] = excl + sum;
-        }
-        __syncthreads();
-        {
-            const uint32_t E = S.eoff[kTileQ];
-            const uint64_t last_km_start = ix.total_len - k;
-            for (uint32_t e = t; e < E; e += kBlock) {
-                // owner item: largest i with eoff[i] <= e
-                uint32_t lo = 0, hi = kTileQ;
-                while (hi - lo > 1) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (S.eoff[mid] <= e) lo = mid; else hi = mid;
-                }
-                const uint32_t i = lo, j = e - S.eoff[i];
-                const uint64_t ent = read_packed(ix.pos, S.slot[i] + j, ix.pos_width);     // sshash.rs:495
-                const uint64_t mm_pos = ent >> 1;
-                const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                const uint64_t off_a = S.off[i];
-                const uint64_t off = (ent & 1) ? k - off_a - w : off_a;                  // class 1: candidate B (:527), class 0: A (:498)
-                if (mm_pos >= off && mm_pos - off <= last_km_start) {
-                    const uint64_t p = mm_pos - off;
-                    const uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
-                    const uint64_t jj = j < 0x7FFFFFFu ? j : 0x7FFFFFFu;
-                    // optimistic: the unitig-boundary check (:509-514) is done once, in S5
-                    if (mt != MZ_NO_MATCH)
-                        atomicMin(&S.best[i], (jj << (kPosBits + 1)) | ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- S4: heavy buckets go through the skew index (sshash.rs:415-433)
-        if (S.cnt_skew != 0) { // uniform
-            const uint32_t ns = S.cnt_skew;
-            __syncthreads();
-            if (ix.has_skew) {
-                for (uint32_t j = t; j < ns; j += kBlock) {
-                    uint32_t i = S.list_b[j];
-                    uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                    S.slot[i] = fw < rc ? fw : rc;
-                    S.list_a[j] = (uint16_t)i;
-                    S.eoff[j] = i; // eoff is free now: remember the heavy items across the level loop
-                }
-                if (t == 0) { S.cnt_a = ns; S.cnt_b = 0; }
-                __syncthreads();
-                tile_mphf(S, ix.skew, false, n_valid);
-                for (uint32_t j = t; j < ns; j += kBlock) {
-                    uint32_t i = S.eoff[j];
-                    if (S.n[i] == kNMiss) continue;
-                    uint64_t p = read_packed(ix.skew_pos, S.slot[i], ix.skew_pos_width);
-                    uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                    uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
-                    if (mt != MZ_NO_MATCH) S.best[i] = ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p;
-                }
-            }
-            __syncthreads();
-        }
-        // ---- S5: materialise results, coalesced 16-byte stores, one tally atomic per wave
+        tile_resolve(S, ix);
+        // ---- S5: coalesced 16-byte stores
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * kBlock + t;
             bool act = i < n_valid;
-            unsigned long long b = S.best[i];
-            mz_k2upos r = make_none();
-            if (act && b != kBestNone) {
-                uint64_t p = b & ((1ull << kPosBits) - 1);
-                UnitigSpan s = locate_unitig(ix.bv_blocks, p);
-                if (p + k <= s.end)
-                    r = make_hit(s, p, ((b >> kPosBits) & 1) ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH);
-                else // first verified candidate straddles two unitigs (sshash.rs:509-514): exact in-order rescan
-                    r = lookup(ix, S.fw[i]);
-            }
+            mz_k2upos r = act ? tile_result(S, ix, i) : make_none();
             if (act) out[base + i] = r;
             tally.add(act && r.match != MZ_NO_MATCH, act && r.match == MZ_NO_MATCH, false);
         }
@@ -344,35 +363,53 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
     tally.flush(counts);
 }
 
-// hits only, compacted per wavefront with a ballot + prefix popcount (K7)
+// hits only, compacted per wavefront with a ballot + prefix popcount (K7); same tile machinery
 __global__ __launch_bounds__(kBlock) void k2u_compact_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
                                                              uint64_t *__restrict__ hit_idx, mz_k2upos *__restrict__ hits,
                                                              unsigned long long *n_hits) {
-    uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        mz_k2upos r = lookup(ix, fw_words[i]);
-        bool hit = r.match != MZ_NO_MATCH;
-        unsigned long long b = __ballot(hit);
-        unsigned long long active = __ballot(1);
-        unsigned lane = __lane_id();
-        unsigned leader = (unsigned)(__ffsll((long long)active) - 1);
-        unsigned long long base = 0;
-        if (lane == leader && b) base = atomicAdd(n_hits, (unsigned long long)__popcll(b));
-        base = __shfl(base, (int)leader);
-        if (hit) {
-            unsigned long long slot = base + __popcll(b & ((1ull << lane) - 1));
-            hit_idx[slot] = i;
-            hits[slot] = r;
+    __shared__ TileLds S;
+    const uint32_t t = threadIdx.x, k = ix.k, w = ix.w;
+    const uint64_t kmask = kmer_mask(k);
+    const uint64_t n_tiles = (n + kTileQ - 1) / kTileQ;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t base = tile * kTileQ;
+        const uint32_t n_valid = (uint32_t)(n - base < (uint64_t)kTileQ ? n - base : (uint64_t)kTileQ);
+        tile_begin(S);
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * kBlock + t;
+            uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
+            uint64_t rc = kmer_rc(fw, k);
+            tile_set_query(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
         }
+        tile_resolve(S, ix);
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * kBlock + t;
+            mz_k2upos r = i < n_valid ? tile_result(S, ix, i) : make_none();
+            bool hit = r.match != MZ_NO_MATCH;
+            unsigned long long b = __ballot(hit);
+            unsigned lane = __lane_id();
+            unsigned long long slot0 = 0;
+            if (lane == 0 && b) slot0 = atomicAdd(n_hits, (unsigned long long)__popcll(b));
+            slot0 = __shfl(slot0, 0);
+            if (hit) {
+                unsigned long long slot = slot0 + __popcll(b & ((1ull << lane) - 1));
+                hit_idx[slot] = base + i;
+                hits[slot] = r;
+            }
+        }
+        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------
-// K: reads (mz_sshash_k2u_reads_device).  One workgroup = 256 consecutive base positions of
-// the concatenated read buffer.  The window is staged in LDS as three bit planes (low code
-// bit, high code bit, invalid) built with wavefront ballots; every w-mer hash of the tile is
-// computed ONCE into LDS (forward and reverse-complement strand) and each lane takes the
-// minimum over its k-w+1 window instead of re-hashing -- the sliding-window minimizer.
+// K: reads (mz_sshash_k2u_reads_device).  One tile = kTileQ consecutive base positions of the
+// concatenated read buffer.  The window is staged in LDS as three bit planes (low code bit, high
+// code bit, invalid) built with wavefront ballots; every w-mer hash of the tile is computed ONCE
+// into LDS (forward and reverse-complement strand) and each position takes the minimum over its
+// k-w+1 window instead of re-hashing -- the sliding-window minimizer.  The lookups then run
+// through the same staged tile machinery as the batch kernel.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t spread_bits(uint32_t x) {
     uint64_t v = x;
@@ -394,147 +431,192 @@ __device__ __forceinline__ uint32_t base_code_dev(uint8_t c) {
     return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
 }
 
-constexpr int kTile = kBlock;           // base positions per workgroup
-constexpr int kTileWords = kTile / 64 + 2; // plane words incl. tail + pad
+constexpr int kPlaneWords = kTileQ / 64 + 2; // plane words incl. the k-1 tail and a pad word
+
+struct ReadsLds {
+    uint64_t plane_lo[kPlaneWords], plane_hi[kPlaneWords], plane_inv[kPlaneWords];
+    uint64_t hf[kTileQ + 32], hr[kTileQ + 32]; // w-mer hashes of the tile, forward / reverse-complement strand
+    uint64_t read0;
+};
 
 __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
                                                            const uint64_t *__restrict__ read_offsets,
                                                            const uint64_t *__restrict__ kmer_offsets, uint64_t n_reads,
                                                            mz_k2upos *__restrict__ out, mz_counts *counts) {
-    __shared__ uint64_t plane_lo[kTileWords], plane_hi[kTileWords], plane_inv[kTileWords];
-    __shared__ uint64_t hf[kTile + 32], hr[kTile + 32];
-    __shared__ uint64_t s_read0;
+    __shared__ TileLds S;
+    __shared__ ReadsLds R;
     const uint32_t k = ix.k, w = ix.w, n_win = k - w + 1;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint64_t B0 = (uint64_t)blockIdx.x * kTile;
-
-    if (t < kTileWords) { plane_lo[t] = 0; plane_hi[t] = 0; plane_inv[t] = 0; }
-    if (t == 0) { // read holding the first base of the tile: largest r with read_offsets[r] <= B0
-        uint64_t lo = 0, hi = n_reads; // invariant: read_offsets[lo] <= B0 (read_offsets[0] == 0)
-        while (hi - lo > 1) {
-            uint64_t mid = (lo + hi) >> 1;
-            if (read_offsets[mid] <= B0) lo = mid; else hi = mid;
+    const uint64_t n_tiles = (n_bases + kTileQ - 1) / kTileQ;
+    Tally tally;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t B0 = tile * kTileQ;
+        tile_begin(S);
+        if (t == 0) { // read holding the first base of the tile: largest r with read_offsets[r] <= B0
+            uint64_t lo = 0, hi = n_reads;
+            while (hi - lo > 1) {
+                uint64_t mid = (lo + hi) >> 1;
+                if (read_offsets[mid] <= B0) lo = mid; else hi = mid;
+            }
+            R.read0 = lo;
         }
-        s_read0 = lo;
-    }
-    __syncthreads();
-    // stage: main 256 positions (one ballot triple per wave) then the k-1 tail (wave 0)
-    {
-        uint64_t b = B0 + t;
-        uint32_t c = b < n_bases ? base_code_dev(bases[b]) : 4u;
-        unsigned long long blo = __ballot(c & 1u), bhi = __ballot((c >> 1) & 1u), binv = __ballot(c >> 2);
-        if (lane == 0) { plane_lo[wave] = blo; plane_hi[wave] = bhi; plane_inv[wave] = binv; }
+        // stage the bit planes: kQpt x 256 positions (one ballot triple per wave and slice) + the k-1 tail
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint64_t b = B0 + (uint64_t)q * kBlock + t;
+            uint32_t c = b < n_bases ? base_code_dev(bases[b]) : 4u;
+            unsigned long long blo = __ballot(c & 1u), bhi = __ballot((c >> 1) & 1u), binv = __ballot(c >> 2);
+            if (lane == 0) { uint32_t wi = q * (kBlock / 64) + wave; R.plane_lo[wi] = blo; R.plane_hi[wi] = bhi; R.plane_inv[wi] = binv; }
+        }
         if (wave == 0) {
-            uint64_t bt = B0 + kTile + lane;
+            uint64_t bt = B0 + kTileQ + lane;
             uint32_t ct = (lane < k - 1 && bt < n_bases) ? base_code_dev(bases[bt]) : 4u;
             unsigned long long tlo = __ballot(ct & 1u), thi = __ballot((ct >> 1) & 1u), tinv = __ballot(ct >> 2);
-            if (lane == 0) { plane_lo[kTile / 64] = tlo; plane_hi[kTile / 64] = thi; plane_inv[kTile / 64] = tinv; }
-        }
-    }
-    __syncthreads();
-    // w-mer hashes of the tile, both strands (positions t and, for the first k-w lanes, kTile+t)
-    for (uint32_t j = t; j < kTile + n_win - 1; j += kBlock) {
-        uint64_t m = spread_bits(plane_window(plane_lo, j, w)) | (spread_bits(plane_window(plane_hi, j, w)) << 1);
-        hf[j] = hash_mmer(m, ix.seed, w);
-        hr[j] = hash_mmer(kmer_rc(m, w), ix.seed, w);
-    }
-    __syncthreads();
-
-    const uint64_t b = B0 + t;
-    bool has_window = false, valid = false;
-    uint64_t out_idx = 0;
-    if (b < n_bases) {
-        uint64_t r = s_read0;
-        while (r + 1 < n_reads && read_offsets[r + 1] <= b) ++r;
-        uint64_t rs = read_offsets[r], re = read_offsets[r + 1];
-        if (b >= rs && b + k <= re) {
-            has_window = true;
-            out_idx = kmer_offsets[r] + (b - rs);
-            valid = plane_window(plane_inv, t, k) == 0;
-        }
-    }
-    mz_k2upos res = make_none();
-    if (has_window) {
-        if (valid) {
-            uint64_t fw = spread_bits(plane_window(plane_lo, t, k)) | (spread_bits(plane_window(plane_hi, t, k)) << 1);
-            uint64_t rc = kmer_rc(fw, k);
-            Minimizer mn;
-            if (fw <= rc) { // g* = fw: leftmost minimum of the forward hashes
-                uint32_t bo = 0;
-                uint64_t bh = hf[t];
-                for (uint32_t o = 1; o < n_win; ++o) {
-                    uint64_t h = hf[t + o];
-                    if (h < bh) { bh = h; bo = o; }
-                }
-                mn.offset = bo;
-                mn.word = (fw >> (2 * bo)) & kmer_mask(w);
-            } else { // g* = rc: offset o of g* is forward position t + (k-w-o); leftmost o == rightmost j
-                uint32_t bj = 0;
-                uint64_t bh = hr[t];
-                for (uint32_t j = 1; j < n_win; ++j) {
-                    uint64_t h = hr[t + j];
-                    if (h <= bh) { bh = h; bj = j; }
-                }
-                mn.offset = (k - w) - bj;
-                mn.word = (rc >> (2 * mn.offset)) & kmer_mask(w);
+            if (lane == 0) {
+                R.plane_lo[kTileQ / 64] = tlo; R.plane_hi[kTileQ / 64] = thi; R.plane_inv[kTileQ / 64] = tinv;
+                R.plane_lo[kTileQ / 64 + 1] = 0; R.plane_hi[kTileQ / 64 + 1] = 0; R.plane_inv[kTileQ / 64 + 1] = ~0ull;
             }
-            res = lookup_with_minimizer(ix, fw, rc, mn);
-        } else {
-            res.match = MZ_SKIPPED;
         }
-        out[out_idx] = res;
+        __syncthreads();
+        // w-mer hashes of the tile, both strands
+        for (uint32_t j = t; j < kTileQ + n_win - 1; j += kBlock) {
+            uint64_t m = spread_bits(plane_window(R.plane_lo, j, w)) | (spread_bits(plane_window(R.plane_hi, j, w)) << 1);
+            R.hf[j] = hash_mmer(m, ix.seed, w);
+            R.hr[j] = hash_mmer(kmer_rc(m, w), ix.seed, w);
+        }
+        __syncthreads();
+        // S0: one item per base position
+        uint64_t out_idx[kQpt];
+        uint32_t state[kQpt]; // 0 = no window here, 1 = window with a non-ACGT byte, 2 = valid k-mer
+        uint64_t r = R.read0;
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            const uint32_t i = q * kBlock + t;
+            const uint64_t b = B0 + i;
+            state[q] = 0;
+            out_idx[q] = 0;
+            uint64_t fw = 0;
+            Minimizer mn{0, 0};
+            if (b < n_bases) {
+                while (r + 1 < n_reads && read_offsets[r + 1] <= b) ++r;
+                uint64_t rs = read_offsets[r], re = read_offsets[r + 1];
+                if (b >= rs && b + k <= re) {
+                    out_idx[q] = kmer_offsets[r] + (b - rs);
+                    state[q] = plane_window(R.plane_inv, i, k) == 0 ? 2u : 1u;
+                }
+            }
+            if (state[q] == 2) {
+                fw = spread_bits(plane_window(R.plane_lo, i, k)) | (spread_bits(plane_window(R.plane_hi, i, k)) << 1);
+                uint64_t rc = kmer_rc(fw, k);
+                if (fw <= rc) { // g* = fw: leftmost minimum of the forward hashes
+                    uint32_t bo = 0;
+                    uint64_t bh = R.hf[i];
+                    for (uint32_t o = 1; o < n_win; ++o) {
+                        uint64_t h = R.hf[i + o];
+                        if (h < bh) { bh = h; bo = o; }
+                    }
+                    mn.offset = bo;
+                    mn.word = (fw >> (2 * bo)) & kmer_mask(w);
+                } else { // g* = rc: offset o of g* is forward position i + (k-w-o); leftmost o == rightmost j
+                    uint32_t bj = 0;
+                    uint64_t bh = R.hr[i];
+                    for (uint32_t j = 1; j < n_win; ++j) {
+                        uint64_t h = R.hr[i + j];
+                        if (h <= bh) { bh = h; bj = j; }
+                    }
+                    mn.offset = (k - w) - bj;
+                    mn.word = (rc >> (2 * mn.offset)) & kmer_mask(w);
+                }
+            }
+            tile_set_query(S, i, fw, mn, state[q] == 2);
+        }
+        tile_resolve(S, ix);
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            const uint32_t i = q * kBlock + t;
+            mz_k2upos res = make_none();
+            if (state[q] == 2) res = tile_result(S, ix, i);
+            else if (state[q] == 1) res.match = MZ_SKIPPED;
+            if (state[q] != 0) out[out_idx[q]] = res;
+            tally.add(state[q] == 2 && res.match != MZ_NO_MATCH, state[q] == 2 && res.match == MZ_NO_MATCH, state[q] == 1);
+        }
+        __syncthreads();
     }
-    Tally tally;
-    tally.add(has_window && valid && res.match != MZ_NO_MATCH, has_window && valid && res.match == MZ_NO_MATCH, has_window && !valid);
     tally.flush(counts);
 }
 
 // ------------------------------------------------------------------------------------
-// K: validate_self on the device (kphf/mod.rs:69-139): thread per global base position
+// K: validate_self on the device (kphf/mod.rs:69-139).  One tile = kTileQ/2 consecutive global base
+// positions, each queried as km (items 0..) and km.swap() (items kTileQ/2..) through the tile
+// machinery; the expected (unitig, offset, length) comes from the plain `starts` array, which the
+// lookup path never reads.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, unsigned long long *report) {
+    __shared__ TileLds S;
     __shared__ uint64_t s_uid0;
-    const uint32_t k = ix.k;
-    const uint64_t P0 = (uint64_t)blockIdx.x * kBlock;
-    if (threadIdx.x == 0) {
-        uint64_t lo = 0, hi = ix.n_unitigs;
-        while (hi - lo > 1) {
-            uint64_t mid = (lo + hi) >> 1;
-            if (ix.starts[mid] <= P0) lo = mid; else hi = mid;
-        }
-        s_uid0 = lo;
-    }
-    __syncthreads();
-    const uint64_t p = P0 + threadIdx.x;
+    constexpr int kPos = kTileQ / 2, kPpt = kQpt / 2;
+    const uint32_t t = threadIdx.x, k = ix.k, w = ix.w;
+    const uint64_t n_tiles = (ix.total_len + kPos - 1) / kPos;
     unsigned n_k = 0, n_fail = 0, n_dup = 0;
-    if (p + k <= ix.total_len) {
-        uint64_t ui = s_uid0;
-        while (ix.starts[ui + 1] <= p) ++ui;
-        uint64_t us = ix.starts[ui], ue = ix.starts[ui + 1];
-        if (p + k <= ue) {
-            n_k = 1;
-            uint64_t fw = read_kmer(ix.useq, p, k), rc = kmer_rc(fw, k);
-            for (int o = 0; o < 2; ++o) { // km, then km.swap()
-                uint64_t q = o ? rc : fw;
-                mz_k2upos r = lookup(ix, q);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t P0 = tile * kPos;
+        tile_begin(S);
+        if (t == 0) {
+            uint64_t lo = 0, hi = ix.n_unitigs;
+            while (hi - lo > 1) {
+                uint64_t mid = (lo + hi) >> 1;
+                if (ix.starts[mid] <= P0) lo = mid; else hi = mid;
+            }
+            s_uid0 = lo;
+        }
+        __syncthreads();
+        uint64_t ui[kPpt], us[kPpt], ue[kPpt];
+        bool valid[kPpt];
+        uint64_t u = s_uid0;
+#pragma unroll
+        for (int q = 0; q < kPpt; ++q) {
+            const uint32_t i = q * kBlock + t;
+            const uint64_t p = P0 + i;
+            valid[q] = false;
+            ui[q] = us[q] = ue[q] = 0;
+            uint64_t fw = 0, rc = 0;
+            if (p + k <= ix.total_len) {
+                while (ix.starts[u + 1] <= p) ++u;
+                ui[q] = u; us[q] = ix.starts[u]; ue[q] = ix.starts[u + 1];
+                valid[q] = p + k <= ue[q];
+                if (valid[q]) { fw = read_kmer(ix.useq, p, k); rc = kmer_rc(fw, k); }
+            }
+            Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
+            tile_set_query(S, i, fw, mn, valid[q]);          // km
+            tile_set_query(S, kPos + i, rc, mn, valid[q]);   // km.swap(): same canonical k-mer, same minimizer
+        }
+        tile_resolve(S, ix);
+#pragma unroll
+        for (int q = 0; q < kPpt; ++q) {
+            if (!valid[q]) continue;
+            const uint32_t i = q * kBlock + t;
+            const uint64_t p = P0 + i;
+            ++n_k;
+            for (int o = 0; o < 2; ++o) {
+                mz_k2upos r = tile_result(S, ix, o ? kPos + i : i);
                 uint32_t want = o ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH;
-                bool ok = r.match == want && r.unitig_id == (uint32_t)ui && r.pos == (uint32_t)(p - us) &&
-                          r.unitig_len == (uint32_t)(ue - us);
+                bool ok = r.match == want && r.unitig_id == (uint32_t)ui[q] && r.pos == (uint32_t)(p - us[q]) &&
+                          r.unitig_len == (uint32_t)(ue[q] - us[q]);
                 if (!ok) {
                     bool dup = false;
                     if (r.match != MZ_NO_MATCH && r.unitig_id < ix.n_unitigs) {
                         uint64_t at = ix.starts[r.unitig_id] + r.pos;
-                        if (at + k <= ix.total_len) {
-                            uint64_t kw = read_kmer(ix.useq, at, k);
-                            dup = (kw == fw || kw == rc) && at != p;
+                        if (at + k <= ix.total_len && at != p) {
+                            uint64_t kw = read_kmer(ix.useq, at, k), fw = S.fw[i];
+                            dup = kw == fw || kw == kmer_rc(fw, k);
                         }
                     }
                     if (dup) ++n_dup; else { ++n_fail; atomicMin(&report[3], (unsigned long long)p); }
                 }
             }
         }
+        __syncthreads();
     }
-    // wave reduce with ballots over the three small counters
     for (int off = 32; off > 0; off >>= 1) {
         n_k += __shfl_down(n_k, off);
         n_fail += __shfl_down(n_fail, off);
@@ -659,12 +741,16 @@ int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_
     return MZ_OK;
 }
 
+static unsigned tile_grid(const DeviceIndex &d, uint64_t n_tiles, unsigned blocks_per_cu) {
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)d.n_cu * blocks_per_cu));
+}
+
 int launch_k2u_compact(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, uint64_t *d_hit_idx, mz_k2upos *d_hits,
                        uint64_t *d_n_hits, hipStream_t stream) {
     if (n == 0) return MZ_OK;
     MZ_HIP_CHECK(hipSetDevice(d.device));
-    hipLaunchKernelGGL(k2u_compact_kernel, dim3(grid_for(d, n, 32)), dim3(kBlock), 0, stream, d.view, d_fw, n, d_hit_idx, d_hits,
-                       (unsigned long long *)d_n_hits);
+    hipLaunchKernelGGL(k2u_compact_kernel, dim3(tile_grid(d, (n + kTileQ - 1) / kTileQ, 16)), dim3(kBlock), 0, stream, d.view, d_fw, n,
+                       d_hit_idx, d_hits, (unsigned long long *)d_n_hits);
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;
 }
@@ -674,25 +760,16 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
                      mz_counts *d_counts, hipStream_t stream) {
     if (n_bases == 0 || n_reads == 0) return MZ_OK;
     MZ_HIP_CHECK(hipSetDevice(d.device));
-    uint64_t n_tiles = (n_bases + kTile - 1) / kTile;
-    if (n_tiles > 0x7FFFFFFFull) {
-        set_error("reads batch too large (%llu bases)", (unsigned long long)n_bases);
-        return MZ_EINVAL;
-    }
-    hipLaunchKernelGGL(k2u_reads_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, stream, d.view, d_bases, n_bases,
-                       d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
+    hipLaunchKernelGGL(k2u_reads_kernel, dim3(tile_grid(d, (n_bases + kTileQ - 1) / kTileQ, 8)), dim3(kBlock), 0, stream, d.view, d_bases,
+                       n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;
 }
 
 int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, hipStream_t stream) {
     MZ_HIP_CHECK(hipSetDevice(d.device));
-    uint64_t n_blocks = (d.view.total_len + kBlock - 1) / kBlock;
-    if (n_blocks > 0x7FFFFFFFull) {
-        set_error("validate_self: sequence too long for one launch");
-        return MZ_EINVAL;
-    }
-    hipLaunchKernelGGL(validate_self_kernel, dim3((unsigned)n_blocks), dim3(kBlock), 0, stream, d.view,
+    uint64_t n_tiles = (d.view.total_len + kTileQ / 2 - 1) / (kTileQ / 2);
+    hipLaunchKernelGGL(validate_self_kernel, dim3(tile_grid(d, n_tiles, 16)), dim3(kBlock), 0, stream, d.view,
                        (unsigned long long *)d_report);
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;

@@ -647,13 +647,15 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
         uint64_t *PV = posv.data();
         const uint64_t *S = slot.data(), *P = psum.data(), *R = range.data();
         const Occ *O = occs.data();
+        const uint64_t total_len_ = us.total_len;
         parallel_for(nt, n_mm, [=](int, uint64_t b, uint64_t e) {
             for (uint64_t i = b; i < e; ++i) {
                 uint64_t d = P[S[i]];
-                for (uint64_t j = R[i]; j < R[i + 1]; ++j) PV[d++] = O[j].pos;
+                for (uint64_t j = R[i]; j < R[i + 1]; ++j)
+                    PV[d++] = make_entry(O[j].pos >> 1, (uint32_t)(O[j].pos & 1), flank_of(useq, total_len_, O[j].pos >> 1, w));
             }
         });
-        max_pos = us.total_len * 2 + 1; // (position << 1) | class
+        max_pos = make_entry(us.total_len, 1, 0xFFFF);
     }
     // 6. skew index (sshash.rs:221-296): k-mers around every occurrence of a heavy minimizer
     if (skew_param != ~0ull) {
@@ -747,7 +749,7 @@ uint64_t SSHashHost::num_bits() const {
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '2'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '3'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>
