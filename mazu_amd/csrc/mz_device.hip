@@ -93,6 +93,10 @@ constexpr int kQpt = 4;                  // queries per thread
 constexpr int kTileQ = kBlock * kQpt;    // queries per tile
 constexpr unsigned long long kBestNone = ~0ull;
 constexpr uint32_t kPosBits = 36;
+#ifndef MZ_SPECULATE
+#define MZ_SPECULATE 1
+#endif
+constexpr bool kSpeculate = MZ_SPECULATE != 0;
 // S.n[i]: bucket size (< kNSkew), or one of the markers below (kNIdle: no query in this slot)
 constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu;
 
@@ -171,6 +175,7 @@ __device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool de
     }
     uint16_t *cur = S.list_a, *nxt = S.list_b;
     uint32_t *ccur = &S.cnt_a, *cnxt = &S.cnt_b;
+    uint32_t round = 0;
     for (;;) {
         __syncthreads();
         const uint32_t count = *ccur;
@@ -181,19 +186,31 @@ __device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool de
             if (t == 0) *ccur = 0;
             break;
         }
-        const bool two = lv + 1 < m.n_levels; // probe two levels per round (speculative second)
-        const MphfLevel L0 = m.levels[lv], L1 = m.levels[two ? lv + 1 : lv];
+        // levels probed per round grow 2, 4, 4, ...: the later (sparser) the list, the more levels are
+        // issued speculatively at once, so the tail of the geometric distribution costs few rounds
+        const uint32_t want = !kSpeculate ? 1u : (round == 0 ? 2u : 4u);
+        const uint32_t nl = m.n_levels - lv < want ? m.n_levels - lv : want;
+        MphfLevel L[4];
+#pragma unroll
+        for (uint32_t a = 0; a < 4; ++a) L[a] = m.levels[lv + (a < nl ? a : 0)];
         for (uint32_t j = t; j < ((count + 63) & ~63u); j += kBlock) {
             bool act = j < count;
             uint32_t i = act ? cur[j] : 0;
             uint64_t key = S.slot[i];
-            MphfProbe p0 = mphf_issue(m, L0, key), p1 = mphf_issue(m, L1, key);
-            uint64_t idx;
-            bool hit = mphf_eval(p0, idx) || (two && mphf_eval(p1, idx));
+            MphfProbe pr[4];
+#pragma unroll
+            for (uint32_t a = 0; a < 4; ++a)
+                if (a < nl) pr[a] = mphf_issue(m, L[a], key);
+            uint64_t idx = 0;
+            bool hit = false;
+#pragma unroll
+            for (uint32_t a = 0; a < 4; ++a)
+                if (a < nl && !hit) hit = mphf_eval(pr[a], idx);
             if (act && hit) S.slot[i] = idx;
             wave_push(nxt, cnxt, act && !hit, i);
         }
-        lv += two ? 2 : 1;
+        ++round;
+        lv += nl;
         __syncthreads();
         if (t == 0) *ccur = 0;
         uint16_t *tl = cur; cur = nxt; nxt = tl;
@@ -265,28 +282,52 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
     {
         const uint32_t E = S.eoff[kTileQ];
         const uint64_t last_km_start = ix.total_len - k;
-        for (uint32_t e = t; e < E; e += kBlock) {
-            uint32_t lo = 0, hi = kTileQ; // owner item: largest i with eoff[i] <= e
-            while (hi - lo > 1) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (S.eoff[mid] <= e) lo = mid; else hi = mid;
+        constexpr int kEpt = 4; // entries in flight per lane: the `pos` gathers are issued together, then the sequence gathers
+        for (uint32_t e0 = t; e0 < E; e0 += kBlock * kEpt) {
+            uint32_t own[kEpt], jdx[kEpt];
+            uint64_t ent[kEpt];
+#pragma unroll
+            for (int a = 0; a < kEpt; ++a) {
+                const uint32_t e = e0 + a * kBlock;
+                own[a] = 0; jdx[a] = 0; ent[a] = 0;
+                if (e < E) {
+                    uint32_t lo = 0, hi = kTileQ; // owner item: largest i with eoff[i] <= e
+                    while (hi - lo > 1) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        if (S.eoff[mid] <= e) lo = mid; else hi = mid;
+                    }
+                    own[a] = lo;
+                    jdx[a] = e - S.eoff[lo];
+                    ent[a] = read_packed(ix.pos, S.slot[lo] + jdx[a], ix.pos_width);           // sshash.rs:495
+                }
             }
-            const uint32_t i = lo, j = e - S.eoff[i];
-            const uint64_t ent = read_packed(ix.pos, S.slot[i] + j, ix.pos_width);     // sshash.rs:495
-            const bool cls = (ent >> kEntryFlankBits) & 1;
-            const uint64_t mm_pos = ent >> kEntryShift;
-            const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-            const uint64_t off_a = S.off[i];
-            const uint64_t off = cls ? k - off_a - w : off_a;                        // class 1: candidate B (:527), class 0: A (:498)
-            const uint64_t X = cls ? (fw <= rc ? rc : fw) : (fw <= rc ? fw : rc);     // expected word on the unitig strand
-            // flank filter: foreign entries of the bucket are dropped without a sequence gather
-            if (flank_ok(X, (uint32_t)off, k, w, (uint32_t)(ent & 0xFFFFu)) && mm_pos >= off && mm_pos - off <= last_km_start) {
-                const uint64_t p = mm_pos - off;
-                const uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
-                const uint64_t jj = j < 0x7FFFFFFu ? j : 0x7FFFFFFu;
+            uint64_t kw[kEpt], pp[kEpt];
+            bool cand[kEpt];
+#pragma unroll
+            for (int a = 0; a < kEpt; ++a) {
+                const uint32_t i = own[a];
+                const bool cls = (ent[a] >> kEntryFlankBits) & 1;
+                const uint64_t mm_pos = ent[a] >> kEntryShift;
+                const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+                const uint64_t off_a = S.off[i];
+                const uint64_t off = cls ? k - off_a - w : off_a;                    // class 1: candidate B (:527), class 0: A (:498)
+                const uint64_t X = cls ? (fw <= rc ? rc : fw) : (fw <= rc ? fw : rc); // expected word on the unitig strand
+                // flank filter: foreign entries of the bucket are dropped without a sequence gather
+                cand[a] = e0 + a * kBlock < E && flank_ok(X, (uint32_t)off, k, w, (uint32_t)(ent[a] & 0xFFFFu)) && mm_pos >= off &&
+                          mm_pos - off <= last_km_start;
+                pp[a] = mm_pos - off;
+                kw[a] = cand[a] ? read_kmer(ix.useq, pp[a], k) : 0;
+            }
+#pragma unroll
+            for (int a = 0; a < kEpt; ++a) {
+                if (!cand[a]) continue;
+                const uint32_t i = own[a];
+                const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+                const uint32_t mt = word_equivalency(fw, rc, kw[a]);
+                const uint64_t jj = jdx[a] < 0x7FFFFFFu ? jdx[a] : 0x7FFFFFFu;
                 // optimistic: the unitig-boundary check (:509-514) is done once, in tile_result
                 if (mt != MZ_NO_MATCH)
-                    atomicMin(&S.best[i], (jj << (kPosBits + 1)) | ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p);
+                    atomicMin(&S.best[i], (jj << (kPosBits + 1)) | ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | pp[a]);
             }
         }
     }
