@@ -188,7 +188,7 @@ struct MphfView {
     const uint64_t *blocks; // n_total_blocks * 8 words
     const MphfLevel *levels;
     uint32_t n_levels;
-    uint32_t pad;
+    uint32_t direct;        // != 0: `blocks` is a direct-address rank bitmap over the key universe (see direct_lookup)
     uint64_t n_keys;
 };
 
@@ -296,8 +296,42 @@ struct IndexView {
 };
 
 // ---- structure probes (used by both sides) -------------------------------------------
+// Direct-address monotone MPHF, used when the key universe is small (w-mers with 2w <= 32 bits):
+// one bit per possible key, set for members, in 64-byte blocks of w0 = ones before the block and
+// w1..w7 = 448 key bits.  index = rank(key): a minimal perfect hash (order preserving) that also
+// answers membership exactly -- ONE line per probe, and a foreign key stops right here, where
+// boomphf's try_hash (sshash.rs:478) would usually hand back a false-positive slot.
+constexpr uint32_t kDirectBitsPerBlock = 448;
+MZ_HD bool direct_lookup(const uint64_t *blocks, uint64_t key, uint64_t &idx) {
+    const uint32_t x = (uint32_t)key;
+    const uint32_t blk = x / kDirectBitsPerBlock, bit = x - blk * kDirectBitsPerBlock;
+    const uint64_t *b = blocks + (uint64_t)blk * 8;
+    uint64_t L[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 8; ++j) L[j] = b[j];
+    const uint32_t dw = bit >> 6, bi = bit & 63;
+    uint32_t r = 0;
+    bool set = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t j = 0; j < 7; ++j) {
+        const uint64_t wv = L[1 + j];
+        if (j < dw) r += popc64(wv);
+        if (j == dw) {
+            set = (wv >> bi) & 1;
+            r += popc64(bi ? (wv & ((1ull << bi) - 1)) : 0);
+        }
+    }
+    idx = L[0] + r;
+    return set;
+}
+
 // MPHF probe == boomphf try_hash: first level whose bit for the key is set gives the index.
 MZ_HD bool mphf_lookup(const MphfView &m, uint64_t key, uint64_t &idx) {
+    if (m.direct) return direct_lookup(m.blocks, key, idx);
     for (uint32_t lv = 0; lv < m.n_levels; ++lv) {
         const MphfLevel L = m.levels[lv];
         uint32_t blk, bit;

@@ -236,8 +236,20 @@ __device__ __forceinline__ void tile_set_query(TileLds &S, uint32_t i, uint64_t 
 __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
     const uint32_t t = threadIdx.x, k = ix.k, w = ix.w;
     __syncthreads();
-    // ---- S1: minimizer MPHF
-    tile_mphf(S, ix.mm, true);
+    // ---- S1: minimizer -> bucket id.  Direct-address rank bitmap (2w <= 32): one dense gather, no rounds;
+    //          otherwise the BBHash level loop
+    if (ix.mm.direct) {
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * kBlock + t;
+            if (S.n[i] < kNIdle) {
+                uint64_t idx;
+                if (direct_lookup(ix.mm.blocks, S.slot[i], idx)) S.slot[i] = idx; else S.n[i] = kNMiss;
+            }
+        }
+    } else {
+        tile_mphf(S, ix.mm, true);
+    }
     // ---- S2: bucket range from the partitioned Elias-Fano prefix sums
 #pragma unroll
     for (int q = 0; q < kQpt; ++q) {

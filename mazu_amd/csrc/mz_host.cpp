@@ -233,6 +233,7 @@ int BlockedEF::build(const uint64_t *xs, uint64_t n_, int n_threads) {
 // ------------------------------------------------------------------ MPHF
 int Mphf::build(const uint64_t *keys_in, uint64_t n, double gamma, int n_threads) {
     n_keys = n;
+    direct = 0;
     blocks.clear();
     levels.clear();
     std::vector<uint64_t> keys(keys_in, keys_in + n), next_keys;
@@ -315,6 +316,36 @@ int Mphf::build(const uint64_t *keys_in, uint64_t n, double gamma, int n_threads
         return MZ_EINVAL;
     }
     if (blocks.empty()) blocks.assign(8, 0); // never hand out a null pointer
+    return MZ_OK;
+}
+
+int Mphf::build_direct(const uint64_t *keys, uint64_t n, uint32_t key_bits, int n_threads) {
+    if (key_bits > 32) {
+        set_error("direct MPHF: key universe of 2^%u too large", key_bits);
+        return MZ_EINVAL;
+    }
+    n_keys = n;
+    direct = 1;
+    levels.clear();
+    uint64_t universe = 1ull << key_bits;
+    uint64_t nb = (universe + kDirectBitsPerBlock - 1) / kDirectBitsPerBlock + 1;
+    blocks.assign(nb * 8, 0);
+    uint64_t *B = blocks.data();
+    parallel_for(n_threads, n, [=](int, uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) {
+            uint32_t x = (uint32_t)keys[i], blk = x / kDirectBitsPerBlock, bit = x - blk * kDirectBitsPerBlock;
+            __atomic_fetch_or(&B[(uint64_t)blk * 8 + 1 + (bit >> 6)], 1ull << (bit & 63), __ATOMIC_RELAXED);
+        }
+    });
+    uint64_t run = 0;
+    for (uint64_t j = 0; j < nb; ++j) {
+        B[j * 8] = run;
+        for (int q = 1; q < 8; ++q) run += popc64(B[j * 8 + q]);
+    }
+    if (run != n) {
+        set_error("direct MPHF: %llu distinct keys of %llu", (unsigned long long)run, (unsigned long long)n);
+        return MZ_EINVAL;
+    }
     return MZ_OK;
 }
 
@@ -622,7 +653,14 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     range.push_back(n_occ);
     n_minimizers = n_mm;
     // 3. MPHF over the minimizer set, gamma = 1.7 (sshash.rs:177)
-    int rc = mm.build(mm_set.data(), n_mm, 1.7, nt);
+    // 2w <= 32: direct-address monotone MPHF (one line per probe, exact membership); else BBHash levels
+    //   (only while the bitmap stays small next to the key set: at most max(32 MiB, 8 B per key))
+    bool use_direct = 2 * w <= 32;
+    if (use_direct) {
+        uint64_t bitmap_bytes = ((1ull << (2 * w)) / kDirectBitsPerBlock + 2) * 64;
+        use_direct = bitmap_bytes <= std::max<uint64_t>(32ull << 20, 8 * n_mm);
+    }
+    int rc = use_direct ? mm.build_direct(mm_set.data(), n_mm, 2 * w, nt) : mm.build(mm_set.data(), n_mm, 1.7, nt);
     if (rc != MZ_OK) return rc;
     // 4. bucket sizes in hash order -> prefix sums (sshash.rs:179-189)
     std::vector<uint64_t> slot(n_mm), psum(n_mm + 1, 0);
@@ -749,7 +787,7 @@ uint64_t SSHashHost::num_bits() const {
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '3'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '4'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>
@@ -767,8 +805,8 @@ static bool getv(std::ifstream &f, std::vector<T> &v) {
     v.resize(n);
     return (bool)f.read((char *)v.data(), n * sizeof(T));
 }
-static void put_mphf(std::ofstream &f, const Mphf &m) { put(f, m.n_keys); putv(f, m.blocks); putv(f, m.levels); }
-static bool get_mphf(std::ifstream &f, Mphf &m) { return get(f, m.n_keys) && getv(f, m.blocks) && getv(f, m.levels); }
+static void put_mphf(std::ofstream &f, const Mphf &m) { put(f, m.n_keys); put(f, m.direct); putv(f, m.blocks); putv(f, m.levels); }
+static bool get_mphf(std::ifstream &f, Mphf &m) { return get(f, m.n_keys) && get(f, m.direct) && getv(f, m.blocks) && getv(f, m.levels); }
 static void put_ef(std::ofstream &f, const EFVector &e) { put(f, e.u); put(f, e.n); put(f, e.n_high_bits); put(f, e.l); putv(f, e.high); putv(f, e.sel); putv(f, e.low); }
 static bool get_ef(std::ifstream &f, EFVector &e) { return get(f, e.u) && get(f, e.n) && get(f, e.n_high_bits) && get(f, e.l) && getv(f, e.high) && getv(f, e.sel) && getv(f, e.low); }
 static void put_pv(std::ofstream &f, const PackedVec &p) { put(f, p.n); put(f, p.width); putv(f, p.w); }

@@ -54,9 +54,12 @@ struct Mphf {
     std::vector<uint64_t> blocks;
     std::vector<MphfLevel> levels;
     uint64_t n_keys = 0;
+    uint32_t direct = 0;
     // keys must be distinct; returns MZ_OK or MZ_EINVAL (too many levels)
     int build(const uint64_t *keys, uint64_t n, double gamma, int n_threads);
-    MphfView view() const { return MphfView{blocks.data(), levels.data(), (uint32_t)levels.size(), 0, n_keys}; }
+    // direct-address variant for keys < 2^key_bits (key_bits <= 32): index = rank of the key
+    int build_direct(const uint64_t *keys, uint64_t n, uint32_t key_bits, int n_threads);
+    MphfView view() const { return MphfView{blocks.data(), levels.data(), (uint32_t)levels.size(), direct, n_keys}; }
     bool try_hash(uint64_t key, uint64_t &idx) const { return mphf_lookup(view(), key, idx); }
     uint64_t num_bits() const { return blocks.size() * 64 + levels.size() * sizeof(MphfLevel) * 8; }
 };
