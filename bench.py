@@ -32,7 +32,7 @@ B_ALG = 208.0        # algorithmic bytes per k-mer query on the 50/50 mix (SURVE
 B_ALG_OWN = 152.0    # same accounting for this repository's layout
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-DEFAULT_BATCH = {"s-tiny": 200_000, "s-yeast": 10_000_000, "s-eighth": 50_000_000, "s-human": 125_000_000}
+DEFAULT_BATCH = {"s-tiny": 200_000, "s-yeast": 10_000_000, "s-txome": 50_000_000, "s-eighth": 50_000_000, "s-human": 125_000_000}
 
 
 def log(msg):
@@ -59,6 +59,62 @@ def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads, target_s=8.0):
     return out, n_hit, n, n / dt / 1e6, t_build, dt
 
 
+def bench_reads(args, ix, us, dev, rank, world, D):
+    """BASELINE config 3: reads -> every k-mer window, results identical to independent k2u calls"""
+    k = us["k"]
+    bases, ro = synth.make_reads(us, args.n_reads, args.read_len, seed=2000 + rank, device=dev)
+    ko = synth.kmer_offsets(ro, k)
+    n_win = int(ko[-1])
+    out = torch.empty(n_win * 2, dtype=torch.int64, device=dev)
+    counts = torch.zeros(3, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        ix.k2u_reads_device(bases, ro, ko, out, counts, streaming=True, stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    counts.zero_()
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    D.allreduce_counts(counts)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    n_hit, n_miss, n_skip = counts.cpu().tolist()
+    if rank == 0:
+        total = n_win * world * args.steps
+        res = {"metric": "M k-mers/sec looked up (reads, every window)", "value": round(total / elapsed / 1e6, 2), "unit": "M k-mers/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": f"{args.workload}: {args.n_reads} x {args.read_len} bp reads per GPU per step (50% with 1% substitutions, "
+                                      f"random strand, drawn across unitig junctions), SSHash k=31 m={args.w} skew_param={args.skew}",
+                          "windows_per_gpu_per_step": n_win, "n_kmers": ix.n_kmers()},
+               "hit_fraction": round(n_hit / max(1, n_hit + n_miss), 4), "skipped": n_skip}
+        if world == 1 and not args.no_cpu_baseline:  # parity of a sample of reads against the oracle
+            os.environ["OMP_NUM_THREADS"] = str(M.lib.mz_host_threads())
+            from oracle import oracle as O
+            orc = O.OracleSSHash(us["words"].cpu().numpy().view(np.uint64), us["total_len"], us["starts"].cpu().numpy().view(np.uint64),
+                                 k, args.w, args.skew, args.seed, with_dict=False)
+            n_s = min(args.n_reads, 20000)
+            t0 = time.time()
+            want, ko_h, _ = orc.k2u_reads(bases[: n_s * args.read_len].cpu().numpy(), ro[: n_s + 1].cpu().numpy().astype(np.uint64), streaming=True)
+            dt = time.time() - t0
+            got = out[: 2 * int(ko_h[-1])].cpu().numpy().view(M.K2UPOS_DTYPE)
+            same = got.tobytes() == want.tobytes()
+            res["cpu_baseline"] = {"value": round(len(want) / dt / 1e6, 3), "unit": "M k-mers/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {n_s} reads, single thread, StreamingK2U walk (bin/kphf/main.rs:299-312)",
+                                   "results_identical_to_gpu": same}
+            assert same, "GPU read results differ from the oracle's streaming walk"
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +128,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--validate", action="store_true", help="also run validate_self on the device before timing")
+    ap.add_argument("--mode", default="kmers", choices=["kmers", "reads"],
+                    help="kmers: batched point queries (headline); reads: BASELINE config 3, every window of 150-bp reads "
+                         "through mz_sshash_k2u_reads_device (.as_streaming() semantics)")
+    ap.add_argument("--n-reads", type=int, default=1_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,6 +191,8 @@ def main():
         log(f"validate_self: {validate}")
         assert validate["n_fail"] == 0, validate
 
+    if args.mode == "reads":
+        return bench_reads(args, ix, us, dev, rank, world, D)
     # ---- this rank's shard of the query batch, generated in HBM
     q = synth.make_query_mix(ix, us, batch, seed=1000 + rank, device=dev)
     out = torch.empty(batch * 2, dtype=torch.int64, device=dev)

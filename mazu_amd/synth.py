@@ -22,6 +22,7 @@ PRESETS = {
     # name: n_unitigs, mean extra length, cap, fraction of bases planted, families
     "s-tiny": dict(n_unitigs=300, mean_extra=400.0, cap=5000, plant_frac=0.08, n_families=8),
     "s-yeast": dict(n_unitigs=6000, mean_extra=1985.0, cap=80000, plant_frac=0.08, n_families=64),
+    "s-txome": dict(n_unitigs=1_200_000, mean_extra=90.0, cap=20000, plant_frac=0.04, n_families=512),
     "s-eighth": dict(n_unitigs=36145130 // 8, mean_extra=68.3, cap=33414 - 31, plant_frac=0.08, n_families=2048),
     "s-human": dict(n_unitigs=36145130, mean_extra=68.3, cap=33414 - 31, plant_frac=0.08, n_families=16384),
 }
