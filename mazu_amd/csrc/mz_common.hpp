@@ -218,9 +218,9 @@ struct BefView {
     const uint64_t *ovf;    // 65 words per overflowed block
     uint64_t n;             // number of elements
 };
-MZ_HD void bef_get_pair(const BefView &e, uint64_t i, uint64_t &v0, uint64_t &v1) {
-    const uint64_t *b = e.blocks + (i >> kBefShift) * 8;
-    const uint32_t t = (uint32_t)(i & (kBefSpan - 1));
+// decode elements t and t+1 of one 8-word block; returns false when the block is flagged as
+// overflowed and no overflow table is given (the caller then falls back to another structure)
+MZ_HD bool bef_block_pair(const uint64_t *b, uint32_t t, const uint64_t *ovf, uint64_t &v0, uint64_t &v1) {
     uint64_t L[8];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -229,10 +229,11 @@ MZ_HD void bef_get_pair(const BefView &e, uint64_t i, uint64_t &v0, uint64_t &v1
     const uint64_t hdr = L[0];
     const uint64_t base = hdr & ((1ull << 40) - 1);
     if (hdr >> 63) { // overflow block: plain values
-        const uint64_t *o = e.ovf + base;
+        if (!ovf) return false;
+        const uint64_t *o = ovf + base;
         v0 = o[t];
         v1 = o[t + 1];
-        return;
+        return true;
     }
     const uint32_t l = (uint32_t)((hdr >> 40) & 63);
     // ones number t-1 (element t) and t (element t+1) of the unary high part; element 0 is the base
@@ -273,6 +274,10 @@ MZ_HD void bef_get_pair(const BefView &e, uint64_t i, uint64_t &v0, uint64_t &v1
     uint64_t r_b = ((uint64_t)(p_second - (need + 1)) << l) | lo_b;     // element need+2
     if (t == 0) { v0 = base; v1 = base + r_a; }
     else { v0 = base + r_a; v1 = base + r_b; }
+    return true;
+}
+MZ_HD void bef_get_pair(const BefView &e, uint64_t i, uint64_t &v0, uint64_t &v1) {
+    bef_block_pair(e.blocks + (i >> kBefShift) * 8, (uint32_t)(i & (kBefSpan - 1)), e.ovf, v0, v1);
 }
 
 struct IndexView {
@@ -296,37 +301,39 @@ struct IndexView {
 };
 
 // ---- structure probes (used by both sides) -------------------------------------------
-// Direct-address monotone MPHF, used when the key universe is small (w-mers with 2w <= 32 bits):
-// one bit per possible key, set for members, in 64-byte blocks of w0 = ones before the block and
-// w1..w7 = 448 key bits.  index = rank(key): a minimal perfect hash (order preserving) that also
-// answers membership exactly -- ONE line per probe, and a foreign key stops right here, where
-// boomphf's try_hash (sshash.rs:478) would usually hand back a false-positive slot.
-constexpr uint32_t kDirectBitsPerBlock = 448;
-MZ_HD bool direct_lookup(const uint64_t *blocks, uint64_t key, uint64_t &idx) {
+// Direct-address monotone MPHF + bucket offsets in ONE 128-byte line ("minimizer record"), used when
+// the key universe is small (w-mers with 2w <= 32 bits).  Record r covers keys [256r, 256r+256):
+//   first 64 bytes : w0 = members before this record (== bucket id of its first member),
+//                    w1..w4 = one bit per key, set for members
+//   second 64 bytes: a partitioned-Elias-Fano block (bef_block_pair) with the bucket starts of this
+//                    record's members, psum[w0 .. w0+64]; flagged "overflow" if the record holds more
+//                    than 64 members or does not fit -- then the global BlockedEF is consulted.
+// bucket id = rank(key): a minimal perfect hash (order preserving) that also answers membership
+// exactly, so a foreign w-mer stops after this one line, where boomphf's try_hash (sshash.rs:478)
+// would usually hand back a false-positive slot; and a member needs no second gather for its
+// bucket range (sshash.rs:482-483).  HBM fetches whole 128-byte lines, so the second half is free.
+constexpr uint32_t kMinRecKeysLog2 = 8, kMinRecWords = 16;
+MZ_HD bool direct_lookup(const uint64_t *blocks, uint64_t key, uint64_t &idx, uint32_t *local = nullptr) {
     const uint32_t x = (uint32_t)key;
-    const uint32_t blk = x / kDirectBitsPerBlock, bit = x - blk * kDirectBitsPerBlock;
-    const uint64_t *b = blocks + (uint64_t)blk * 8;
-    uint64_t L[8];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int j = 0; j < 8; ++j) L[j] = b[j];
-    const uint32_t dw = bit >> 6, bi = bit & 63;
-    uint32_t r = 0;
-    bool set = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (uint32_t j = 0; j < 7; ++j) {
-        const uint64_t wv = L[1 + j];
-        if (j < dw) r += popc64(wv);
-        if (j == dw) {
-            set = (wv >> bi) & 1;
-            r += popc64(bi ? (wv & ((1ull << bi) - 1)) : 0);
-        }
-    }
-    idx = L[0] + r;
-    return set;
+    const uint64_t *b = blocks + (uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords;
+    const uint32_t bit = x & ((1u << kMinRecKeysLog2) - 1), dw = bit >> 6, bi = bit & 63;
+    const uint64_t base = b[0], w1 = b[1], w2 = b[2], w3 = b[3], w4 = b[4];
+    const uint64_t wv = dw == 0 ? w1 : dw == 1 ? w2 : dw == 2 ? w3 : w4;
+    uint32_t r = popc64(bi ? (wv & ((1ull << bi) - 1)) : 0);
+    if (dw > 0) r += popc64(w1);
+    if (dw > 1) r += popc64(w2);
+    if (dw > 2) r += popc64(w3);
+    idx = base + r;
+    if (local) *local = r;
+    return (wv >> bi) & 1;
+}
+// member test + bucket id + bucket range from one record; `global` is the fallback for overflowed records
+MZ_HD bool minrec_lookup(const uint64_t *blocks, const BefView &global, uint64_t key, uint64_t &h, uint64_t &ps, uint64_t &pe) {
+    uint32_t local;
+    if (!direct_lookup(blocks, key, h, &local)) return false;
+    const uint64_t *b = blocks + (uint64_t)((uint32_t)key >> kMinRecKeysLog2) * kMinRecWords + 8;
+    if (local >= kBefSpan || !bef_block_pair(b, local, nullptr, ps, pe)) bef_get_pair(global, h, ps, pe);
+    return true;
 }
 
 // MPHF probe == boomphf try_hash: first level whose bit for the key is set gives the index.
@@ -490,10 +497,13 @@ MZ_HD mz_k2upos skew_lookup(const IndexView &ix, uint64_t fw, uint64_t rc) {
 // sshash.rs:478-554 once the canonical minimizer is known
 MZ_HD mz_k2upos lookup_with_minimizer(const IndexView &ix, uint64_t fw, uint64_t rc, Minimizer mn) {
     const uint32_t k = ix.k, w = ix.w;
-    uint64_t h;
-    if (!mphf_lookup(ix.mm, mn.word, h)) return make_none();       // :478-479
-    uint64_t ps, pe;
-    bef_get_pair(ix.buckets, h, ps, pe);                           // :482-483
+    uint64_t h, ps, pe;
+    if (ix.mm.direct) {                                            // :478-483 from one minimizer record
+        if (!minrec_lookup(ix.mm.blocks, ix.buckets, mn.word, h, ps, pe)) return make_none();
+    } else {
+        if (!mphf_lookup(ix.mm, mn.word, h)) return make_none();   // :478-479
+        bef_get_pair(ix.buckets, h, ps, pe);                       // :482-483
+    }
     if (pe - ps > ix.skew_param) return skew_lookup(ix, fw, rc);   // :486-490
     const uint64_t last_km_start = ix.total_len - k;               // :492
     const uint64_t off_a = mn.offset, off_b = k - mn.offset - w;   // :493

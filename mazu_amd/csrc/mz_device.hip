@@ -239,32 +239,42 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
     // ---- S1: minimizer -> bucket id.  Direct-address rank bitmap (2w <= 32): one dense gather, no rounds;
     //          otherwise the BBHash level loop
     if (ix.mm.direct) {
+        // S1+S2 fused: member test, bucket id and bucket range from ONE 128-byte minimizer record
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * kBlock + t;
+            bool heavy = false;
             if (S.n[i] < kNIdle) {
-                uint64_t idx;
-                if (direct_lookup(ix.mm.blocks, S.slot[i], idx)) S.slot[i] = idx; else S.n[i] = kNMiss;
+                uint64_t h, ps, pe;
+                if (minrec_lookup(ix.mm.blocks, ix.buckets, S.slot[i], h, ps, pe)) {
+                    uint64_t cnt = pe - ps;
+                    heavy = cnt > ix.skew_param;                    // sshash.rs:486-490
+                    S.slot[i] = ps;
+                    S.n[i] = heavy ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
+                } else {
+                    S.n[i] = kNMiss;
+                }
             }
+            wave_push(S.list_b, &S.cnt_skew, heavy, i);
         }
     } else {
         tile_mphf(S, ix.mm, true);
-    }
-    // ---- S2: bucket range from the partitioned Elias-Fano prefix sums
+        // ---- S2: bucket range from the partitioned Elias-Fano prefix sums
 #pragma unroll
-    for (int q = 0; q < kQpt; ++q) {
-        uint32_t i = q * kBlock + t;
-        bool act = S.n[i] < kNIdle;
-        bool heavy = false;
-        if (act) {
-            uint64_t ps, pe;
-            bef_get_pair(ix.buckets, S.slot[i], ps, pe);
-            uint64_t cnt = pe - ps;
-            heavy = cnt > ix.skew_param;                        // sshash.rs:486-490
-            S.slot[i] = ps;
-            S.n[i] = heavy ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * kBlock + t;
+            bool act = S.n[i] < kNIdle;
+            bool heavy = false;
+            if (act) {
+                uint64_t ps, pe;
+                bef_get_pair(ix.buckets, S.slot[i], ps, pe);
+                uint64_t cnt = pe - ps;
+                heavy = cnt > ix.skew_param;                        // sshash.rs:486-490
+                S.slot[i] = ps;
+                S.n[i] = heavy ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
+            }
+            wave_push(S.list_b, &S.cnt_skew, heavy, i);
         }
-        wave_push(S.list_b, &S.cnt_skew, heavy, i);
     }
     __syncthreads();
     // ---- S3: flatten bucket entries (exclusive scan of n over the tile, blocked by thread)

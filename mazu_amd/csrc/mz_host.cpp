@@ -166,6 +166,29 @@ int EFVector::build(const uint64_t *xs, uint64_t n_, uint64_t u_) {
 
 
 // ------------------------------------------------------------------ partitioned Elias-Fano
+// Encode xs[0..cnt] (cnt <= 64 elements after the base xs[0]) into one 8-word partitioned-EF block
+// (layout: BefView in mz_common.hpp).  Missing elements are padded with copies of the last value so
+// the unary part always holds 64 ones.  Returns false (W untouched) when it does not fit.
+static bool bef_encode_block(const uint64_t *xs, uint32_t cnt, uint64_t *W) {
+    const uint64_t base = xs[0], span = xs[cnt] - base;
+    uint32_t l = 0;
+    bool fits = false;
+    for (l = span >= kBefSpan ? (uint32_t)msb(span / kBefSpan) : 0; l <= kBefMaxL; ++l) {
+        uint64_t high_bits = (span >> l) + kBefSpan + 1;
+        if (high_bits + 64ull * l <= 448) { fits = true; break; }
+    }
+    if (!fits || base >= (1ull << 40)) return false;
+    for (int q = 0; q < 8; ++q) W[q] = 0;
+    W[0] = base | ((uint64_t)l << 40);
+    for (uint32_t t = 1; t <= kBefSpan; ++t) {
+        uint64_t r = xs[t <= cnt ? t : cnt] - base;
+        uint64_t hb = (r >> l) + (t - 1);
+        W[1 + (hb >> 6)] |= 1ull << (hb & 63);
+        for (uint32_t pl = 0; pl < l; ++pl) W[7 - pl] |= ((r >> pl) & 1) << (t - 1);
+    }
+    return true;
+}
+
 int BlockedEF::build(const uint64_t *xs, uint64_t n_, int n_threads) {
     if (n_ == 0) {
         set_error("Elias-Fano: empty sequence (Error::EFEmpty)");
@@ -190,31 +213,7 @@ int BlockedEF::build(const uint64_t *xs, uint64_t n_, int n_threads) {
         for (uint64_t j = bb; j < be; ++j) {
             uint64_t first = j << kBefShift;
             uint64_t last = std::min<uint64_t>(first + kBefSpan, n - 1); // elements first..last (<= 65)
-            uint64_t base = xs[first], span = xs[last] - base;
-            uint32_t cnt = (uint32_t)(last - first); // elements 1..cnt are encoded
-            uint32_t l = 0;
-            bool fits = false;
-            for (l = span >= kBefSpan ? (uint32_t)msb(span / kBefSpan) : 0; l <= kBefMaxL; ++l) {
-                uint64_t high_bits = (span >> l) + kBefSpan + 1;
-                if (high_bits + 64ull * l <= 448) { fits = true; break; }
-            }
-            uint64_t *W = B + j * 8;
-            if (!fits) { OV[j] = 1; continue; }
-            W[0] = base | ((uint64_t)l << 40);
-            for (uint32_t t = 1; t <= cnt; ++t) {
-                uint64_t r = xs[first + t] - base;
-                uint64_t hb = (r >> l) + (t - 1);
-                W[1 + (hb >> 6)] |= 1ull << (hb & 63);
-                for (uint32_t pl = 0; pl < l; ++pl) W[7 - pl] |= ((r >> pl) & 1) << (t - 1);
-            }
-            // pad the missing elements of a short final block with copies of the last value so that
-            // the unary part always holds 64 ones (selects stay in range)
-            uint64_t rl = xs[last] - base;
-            for (uint32_t t = cnt + 1; t <= kBefSpan; ++t) {
-                uint64_t hb = (rl >> l) + (t - 1);
-                W[1 + (hb >> 6)] |= 1ull << (hb & 63);
-                for (uint32_t pl = 0; pl < l; ++pl) W[7 - pl] |= ((rl >> pl) & 1) << (t - 1);
-            }
+            if (!bef_encode_block(xs + first, (uint32_t)(last - first), B + j * 8)) OV[j] = 1;
         }
     });
     ovf.clear();
@@ -328,25 +327,48 @@ int Mphf::build_direct(const uint64_t *keys, uint64_t n, uint32_t key_bits, int 
     direct = 1;
     levels.clear();
     uint64_t universe = 1ull << key_bits;
-    uint64_t nb = (universe + kDirectBitsPerBlock - 1) / kDirectBitsPerBlock + 1;
-    blocks.assign(nb * 8, 0);
+    uint64_t nr = (universe >> kMinRecKeysLog2) + 1;
+    blocks.assign(nr * kMinRecWords, 0);
     uint64_t *B = blocks.data();
     parallel_for(n_threads, n, [=](int, uint64_t b, uint64_t e) {
         for (uint64_t i = b; i < e; ++i) {
-            uint32_t x = (uint32_t)keys[i], blk = x / kDirectBitsPerBlock, bit = x - blk * kDirectBitsPerBlock;
-            __atomic_fetch_or(&B[(uint64_t)blk * 8 + 1 + (bit >> 6)], 1ull << (bit & 63), __ATOMIC_RELAXED);
+            uint32_t x = (uint32_t)keys[i], bit = x & ((1u << kMinRecKeysLog2) - 1);
+            __atomic_fetch_or(&B[(uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords + 1 + (bit >> 6)], 1ull << (bit & 63), __ATOMIC_RELAXED);
         }
     });
     uint64_t run = 0;
-    for (uint64_t j = 0; j < nb; ++j) {
-        B[j * 8] = run;
-        for (int q = 1; q < 8; ++q) run += popc64(B[j * 8 + q]);
+    for (uint64_t j = 0; j < nr; ++j) {
+        B[j * kMinRecWords] = run;
+        for (int q = 1; q <= 4; ++q) run += popc64(B[j * kMinRecWords + q]);
+        B[j * kMinRecWords + 8] = 1ull << 63; // bucket-offset half: "consult the global structure" until fill_bucket_offsets()
     }
     if (run != n) {
         set_error("direct MPHF: %llu distinct keys of %llu", (unsigned long long)run, (unsigned long long)n);
         return MZ_EINVAL;
     }
     return MZ_OK;
+}
+
+// second half of every minimizer record: the bucket starts psum[rank0 .. rank0+members] of its members
+uint64_t Mphf::fill_bucket_offsets(const uint64_t *psum, uint64_t n_psum, int n_threads) {
+    uint64_t nr = blocks.size() / kMinRecWords;
+    uint64_t *B = blocks.data();
+    std::vector<uint64_t> over(std::max(1, n_threads), 0);
+    uint64_t *OV = over.data();
+    parallel_for(n_threads, nr, [=](int t, uint64_t b, uint64_t e) {
+        for (uint64_t j = b; j < e; ++j) {
+            uint64_t *W = B + j * kMinRecWords;
+            uint32_t c = 0;
+            for (int q = 1; q <= 4; ++q) c += popc64(W[q]);
+            if (c == 0) continue;
+            uint64_t rank0 = W[0];
+            bool ok = c <= kBefSpan && rank0 + c < n_psum && bef_encode_block(psum + rank0, c, W + 8);
+            if (!ok) { W[8] = 1ull << 63; OV[t]++; }
+        }
+    });
+    uint64_t tot = 0;
+    for (auto v : over) tot += v;
+    return tot;
 }
 
 // ------------------------------------------------------------------ UnitigSet
@@ -654,11 +676,11 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     n_minimizers = n_mm;
     // 3. MPHF over the minimizer set, gamma = 1.7 (sshash.rs:177)
     // 2w <= 32: direct-address monotone MPHF (one line per probe, exact membership); else BBHash levels
-    //   (only while the bitmap stays small next to the key set: at most max(32 MiB, 8 B per key))
+    //   (only while the records stay small next to the key set: at most max(64 MiB, 16 B per key))
     bool use_direct = 2 * w <= 32;
     if (use_direct) {
-        uint64_t bitmap_bytes = ((1ull << (2 * w)) / kDirectBitsPerBlock + 2) * 64;
-        use_direct = bitmap_bytes <= std::max<uint64_t>(32ull << 20, 8 * n_mm);
+        uint64_t rec_bytes = (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords * 8;
+        use_direct = rec_bytes <= std::max<uint64_t>(64ull << 20, 16 * n_mm);
     }
     int rc = use_direct ? mm.build_direct(mm_set.data(), n_mm, 2 * w, nt) : mm.build(mm_set.data(), n_mm, 1.7, nt);
     if (rc != MZ_OK) return rc;
@@ -750,6 +772,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     // 7. finish (sshash.rs:310-329): Elias-Fano the prefix sums, bit-pack the positions
     rc = buckets.build(psum.data(), n_mm + 1, nt);
     if (rc != MZ_OK) return rc;
+    if (mm.direct) n_minrec_overflow = mm.fill_bucket_offsets(psum.data(), n_mm + 1, nt);
     pos.assign(posv.data(), n_occ, max_pos, nt);
     build_seconds = now_s() - t0;
     return MZ_OK;
@@ -787,7 +810,7 @@ uint64_t SSHashHost::num_bits() const {
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '4'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '5'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>

@@ -59,6 +59,8 @@ struct Mphf {
     int build(const uint64_t *keys, uint64_t n, double gamma, int n_threads);
     // direct-address variant for keys < 2^key_bits (key_bits <= 32): index = rank of the key
     int build_direct(const uint64_t *keys, uint64_t n, uint32_t key_bits, int n_threads);
+    // direct mode: encode the bucket starts of every record's members into its second half; returns #records left to the global EF
+    uint64_t fill_bucket_offsets(const uint64_t *psum, uint64_t n_psum, int n_threads);
     MphfView view() const { return MphfView{blocks.data(), levels.data(), (uint32_t)levels.size(), direct, n_keys}; }
     bool try_hash(uint64_t key, uint64_t &idx) const { return mphf_lookup(view(), key, idx); }
     uint64_t num_bits() const { return blocks.size() * 64 + levels.size() * sizeof(MphfLevel) * 8; }
@@ -97,7 +99,7 @@ struct SSHashHost {
     bool has_skew = false;
     Mphf skew;        // skew_index.mphf
     PackedVec skew_pos;
-    uint64_t n_minimizers = 0;
+    uint64_t n_minimizers = 0, n_minrec_overflow = 0;
     double build_seconds = 0;
 
     int build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads);
