@@ -392,8 +392,18 @@ __device__ __forceinline__ mz_k2upos tile_result(const TileLds &S, const IndexVi
     return lookup(ix, S.fw[i]); // first verified candidate straddles two unitigs (sshash.rs:509-514): exact in-order rescan
 }
 
+// KW: compile-time (k << 8 | w) for the common configuration (constant shifts, masks and trip counts;
+// fully unrolled minimizer loop), 0 = read k and w from the index
+template <uint32_t KW>
+__device__ __forceinline__ void fix_kw(IndexView &ix) {
+    if (KW != 0) { ix.k = KW >> 8; ix.w = KW & 255; }
+}
+constexpr uint32_t kKW3115 = (31u << 8) | 15u;
+
+template <uint32_t KW>
 __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
                                                           mz_k2upos *__restrict__ out, mz_counts *counts) {
+    fix_kw<KW>(ix);
     __shared__ TileLds S;
     const uint32_t t = threadIdx.x, k = ix.k, w = ix.w;
     const uint64_t kmask = kmer_mask(k);
@@ -502,10 +512,12 @@ struct ReadsLds {
     uint64_t read0;
 };
 
+template <uint32_t KW>
 __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
                                                            const uint64_t *__restrict__ read_offsets,
                                                            const uint64_t *__restrict__ kmer_offsets, uint64_t n_reads,
                                                            mz_k2upos *__restrict__ out, mz_counts *counts) {
+    fix_kw<KW>(ix);
     __shared__ TileLds S;
     __shared__ ReadsLds R;
     const uint32_t k = ix.k, w = ix.w, n_win = k - w + 1;
@@ -614,7 +626,9 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
 // machinery; the expected (unitig, offset, length) comes from the plain `starts` array, which the
 // lookup path never reads.
 // ------------------------------------------------------------------------------------
+template <uint32_t KW>
 __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, unsigned long long *report) {
+    fix_kw<KW>(ix);
     __shared__ TileLds S;
     __shared__ uint64_t s_uid0;
     constexpr int kPos = kTileQ / 2, kPpt = kQpt / 2;
@@ -798,7 +812,10 @@ int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_
     } else {
         uint64_t n_tiles = (n + kTileQ - 1) / kTileQ;
         unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)d.n_cu * 16));
-        hipLaunchKernelGGL(k2u_tile_kernel, dim3(grid), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
+        if (d.view.k == 31 && d.view.w == 15)
+            hipLaunchKernelGGL(k2u_tile_kernel<kKW3115>, dim3(grid), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
+        else
+            hipLaunchKernelGGL(k2u_tile_kernel<0>, dim3(grid), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
     }
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;
@@ -823,8 +840,13 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
                      mz_counts *d_counts, hipStream_t stream) {
     if (n_bases == 0 || n_reads == 0) return MZ_OK;
     MZ_HIP_CHECK(hipSetDevice(d.device));
-    hipLaunchKernelGGL(k2u_reads_kernel, dim3(tile_grid(d, (n_bases + kTileQ - 1) / kTileQ, 8)), dim3(kBlock), 0, stream, d.view, d_bases,
-                       n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
+    const dim3 grid(tile_grid(d, (n_bases + kTileQ - 1) / kTileQ, 8));
+    if (d.view.k == 31 && d.view.w == 15)
+        hipLaunchKernelGGL(k2u_reads_kernel<kKW3115>, grid, dim3(kBlock), 0, stream, d.view, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
+                           n_reads, d_out, d_counts);
+    else
+        hipLaunchKernelGGL(k2u_reads_kernel<0>, grid, dim3(kBlock), 0, stream, d.view, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
+                           n_reads, d_out, d_counts);
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;
 }
@@ -832,8 +854,12 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
 int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, hipStream_t stream) {
     MZ_HIP_CHECK(hipSetDevice(d.device));
     uint64_t n_tiles = (d.view.total_len + kTileQ / 2 - 1) / (kTileQ / 2);
-    hipLaunchKernelGGL(validate_self_kernel, dim3(tile_grid(d, n_tiles, 16)), dim3(kBlock), 0, stream, d.view,
-                       (unsigned long long *)d_report);
+    if (d.view.k == 31 && d.view.w == 15)
+        hipLaunchKernelGGL(validate_self_kernel<kKW3115>, dim3(tile_grid(d, n_tiles, 16)), dim3(kBlock), 0, stream, d.view,
+                           (unsigned long long *)d_report);
+    else
+        hipLaunchKernelGGL(validate_self_kernel<0>, dim3(tile_grid(d, n_tiles, 16)), dim3(kBlock), 0, stream, d.view,
+                           (unsigned long long *)d_report);
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;
 }
