@@ -62,7 +62,7 @@ def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads, target_s=8.0):
 def bench_reads(args, ix, us, dev, rank, world, D):
     """BASELINE config 3: reads -> every k-mer window, results identical to independent k2u calls"""
     k = us["k"]
-    bases, ro = synth.make_reads(us, args.n_reads, args.read_len, seed=2000 + rank, device=dev)
+    bases, ro = synth.make_reads(us, args.n_reads, args.read_len, seed=2000 + rank, device=dev, err_frac=args.err_frac)
     ko = synth.kmer_offsets(ro, k)
     n_win = int(ko[-1])
     out = torch.empty(n_win * 2, dtype=torch.int64, device=dev)
@@ -133,6 +133,7 @@ def main():
                          "through mz_sshash_k2u_reads_device (.as_streaming() semantics)")
     ap.add_argument("--n-reads", type=int, default=1_000_000)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--err-frac", type=float, default=0.5, help="reads mode: fraction of reads with 1%% substitutions")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

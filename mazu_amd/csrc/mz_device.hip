@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "mz_device.hpp"
 
@@ -506,20 +507,57 @@ __device__ __forceinline__ uint32_t base_code_dev(uint8_t c) {
 
 constexpr int kPlaneWords = kTileQ / 64 + 2; // plane words incl. the k-1 tail and a pad word
 
+template <typename H> // H = uint32_t when the w-mer hash has 32 significant bits (w <= 16), else uint64_t
 struct ReadsLds {
     uint64_t plane_lo[kPlaneWords], plane_hi[kPlaneWords], plane_inv[kPlaneWords];
-    uint64_t hf[kTileQ + 32], hr[kTileQ + 32]; // w-mer hashes of the tile, forward / reverse-complement strand
+    H hf[kTileQ + 32], hr[kTileQ + 32]; // w-mer hashes of the tile, forward / reverse-complement strand
     uint64_t read0;
 };
 
+// canonical minimizer of the window at tile position i from the staged w-mer hashes (== canonical_minimizer())
+template <typename H>
+__device__ __forceinline__ Minimizer window_minimizer(const ReadsLds<H> &R, uint32_t i, uint64_t fw, uint64_t rc, uint32_t k, uint32_t w) {
+    const uint32_t n_win = k - w + 1;
+    Minimizer mn;
+    if (fw <= rc) { // g* = fw: leftmost minimum of the forward hashes
+        uint32_t bo = 0;
+        H bh = R.hf[i];
+        for (uint32_t o = 1; o < n_win; ++o) {
+            H h = R.hf[i + o];
+            if (h < bh) { bh = h; bo = o; }
+        }
+        mn.offset = bo;
+        mn.word = (fw >> (2 * bo)) & kmer_mask(w);
+    } else { // g* = rc: offset o of g* is forward position i + (k-w-o); leftmost o == rightmost j
+        uint32_t bj = 0;
+        H bh = R.hr[i];
+        for (uint32_t j = 1; j < n_win; ++j) {
+            H h = R.hr[i + j];
+            if (h <= bh) { bh = h; bj = j; }
+        }
+        mn.offset = (k - w) - bj;
+        mn.word = (rc >> (2 * mn.offset)) & kmer_mask(w);
+    }
+    return mn;
+}
+
+// Every window is an independent lookup through the tile machinery (the loop of bin/kphf/main.rs:314-324).
+// The `.as_streaming()` shortcut of the reference (index/caching.rs:65-103: try prev.pos+1 on the same
+// unitig first) was also built here as "look up one anchor window per 32, extend the rest along the
+// anchor's unitig in both directions, fall back to the lookup": it returned identical results but ran
+// SLOWER than looking every window up (11.0 vs 12.3 G k-mers/s on clean reads over long unitigs, 6.2 vs
+// 8.9 on the junction-heavy s-txome set): with one 128-byte line per negative and ~3 per positive the
+// lookup is cheaper than a second staged pass.  Streaming requests therefore take this same path; by
+// the reference's own contract (and for every unique-k-mer set) the results are the same.
 template <uint32_t KW>
 __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
                                                            const uint64_t *__restrict__ read_offsets,
                                                            const uint64_t *__restrict__ kmer_offsets, uint64_t n_reads,
                                                            mz_k2upos *__restrict__ out, mz_counts *counts) {
     fix_kw<KW>(ix);
+    using H = typename std::conditional<(KW != 0 && (KW & 255u) <= 16u), uint32_t, uint64_t>::type;
     __shared__ TileLds S;
-    __shared__ ReadsLds R;
+    __shared__ ReadsLds<H> R;
     const uint32_t k = ix.k, w = ix.w, n_win = k - w + 1;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint64_t n_tiles = (n_bases + kTileQ - 1) / kTileQ;
@@ -556,13 +594,13 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
         // w-mer hashes of the tile, both strands
         for (uint32_t j = t; j < kTileQ + n_win - 1; j += kBlock) {
             uint64_t m = spread_bits(plane_window(R.plane_lo, j, w)) | (spread_bits(plane_window(R.plane_hi, j, w)) << 1);
-            R.hf[j] = hash_mmer(m, ix.seed, w);
-            R.hr[j] = hash_mmer(kmer_rc(m, w), ix.seed, w);
+            R.hf[j] = (H)hash_mmer(m, ix.seed, w);
+            R.hr[j] = (H)hash_mmer(kmer_rc(m, w), ix.seed, w);
         }
         __syncthreads();
         // S0: one item per base position
         uint64_t out_idx[kQpt];
-        uint32_t state[kQpt]; // 0 = no window here, 1 = window with a non-ACGT byte, 2 = valid k-mer
+        uint32_t state[kQpt]; // 0 = no window here, 1 = window with a non-ACGT byte, 2 = valid k-mer (answer pending)
         uint64_t r = R.read0;
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
@@ -570,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
             const uint64_t b = B0 + i;
             state[q] = 0;
             out_idx[q] = 0;
-            uint64_t fw = 0;
+            uint64_t fw = 0, rc = 0;
             Minimizer mn{0, 0};
             if (b < n_bases) {
                 while (r + 1 < n_reads && read_offsets[r + 1] <= b) ++r;
@@ -580,40 +618,27 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
                     state[q] = plane_window(R.plane_inv, i, k) == 0 ? 2u : 1u;
                 }
             }
-            if (state[q] == 2) {
+            bool query = state[q] == 2;
+            if (query) {
                 fw = spread_bits(plane_window(R.plane_lo, i, k)) | (spread_bits(plane_window(R.plane_hi, i, k)) << 1);
-                uint64_t rc = kmer_rc(fw, k);
-                if (fw <= rc) { // g* = fw: leftmost minimum of the forward hashes
-                    uint32_t bo = 0;
-                    uint64_t bh = R.hf[i];
-                    for (uint32_t o = 1; o < n_win; ++o) {
-                        uint64_t h = R.hf[i + o];
-                        if (h < bh) { bh = h; bo = o; }
-                    }
-                    mn.offset = bo;
-                    mn.word = (fw >> (2 * bo)) & kmer_mask(w);
-                } else { // g* = rc: offset o of g* is forward position i + (k-w-o); leftmost o == rightmost j
-                    uint32_t bj = 0;
-                    uint64_t bh = R.hr[i];
-                    for (uint32_t j = 1; j < n_win; ++j) {
-                        uint64_t h = R.hr[i + j];
-                        if (h <= bh) { bh = h; bj = j; }
-                    }
-                    mn.offset = (k - w) - bj;
-                    mn.word = (rc >> (2 * mn.offset)) & kmer_mask(w);
-                }
+                rc = kmer_rc(fw, k);
+                if (query) mn = window_minimizer(R, i, fw, rc, k, w);
             }
-            tile_set_query(S, i, fw, mn, state[q] == 2);
+            tile_set_query(S, i, fw, mn, query);
+            if (state[q] == 1) { // non-ACGT window: reported, never queried
+                mz_k2upos sk = make_none();
+                sk.match = MZ_SKIPPED;
+                out[out_idx[q]] = sk;
+            }
+            tally.add(false, false, state[q] == 1);
         }
         tile_resolve(S, ix);
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            const uint32_t i = q * kBlock + t;
-            mz_k2upos res = make_none();
-            if (state[q] == 2) res = tile_result(S, ix, i);
-            else if (state[q] == 1) res.match = MZ_SKIPPED;
-            if (state[q] != 0) out[out_idx[q]] = res;
-            tally.add(state[q] == 2 && res.match != MZ_NO_MATCH, state[q] == 2 && res.match == MZ_NO_MATCH, state[q] == 1);
+            const bool pend = state[q] == 2;
+            mz_k2upos res = pend ? tile_result(S, ix, q * kBlock + t) : make_none();
+            if (pend) out[out_idx[q]] = res;
+            tally.add(pend && res.match != MZ_NO_MATCH, pend && res.match == MZ_NO_MATCH, false);
         }
         __syncthreads();
     }
@@ -836,11 +861,12 @@ int launch_k2u_compact(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, u
 }
 
 int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
-                     const uint64_t *d_kmer_offsets, uint64_t n_reads, int /*streaming*/, mz_k2upos *d_out,
+                     const uint64_t *d_kmer_offsets, uint64_t n_reads, int streaming, mz_k2upos *d_out,
                      mz_counts *d_counts, hipStream_t stream) {
     if (n_bases == 0 || n_reads == 0) return MZ_OK;
     MZ_HIP_CHECK(hipSetDevice(d.device));
     const dim3 grid(tile_grid(d, (n_bases + kTileQ - 1) / kTileQ, 8));
+    (void)streaming; // same kernel: see the note above k2u_reads_kernel
     if (d.view.k == 31 && d.view.w == 15)
         hipLaunchKernelGGL(k2u_reads_kernel<kKW3115>, grid, dim3(kBlock), 0, stream, d.view, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
                            n_reads, d_out, d_counts);
