@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmazu_amd.so")
+LIB_PATH = os.environ.get("MZ_LIB") or os.path.join(_HERE, "libmazu_amd.so")  # MZ_LIB: A/B builds of the same ABI
 
 MZ_OK, MZ_EINVAL, MZ_ENOMEM, MZ_EHIP, MZ_EIO, MZ_ENOTMONOTONE, MZ_EEMPTY = range(7)
 MZ_NO_SKEW_INDEX = 2**64 - 1
