@@ -137,7 +137,9 @@ uint64_t mz_sshash_num_bits(const mz_sshash *ix);
 /* bytes resident in HBM once uploaded */
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix);
 
-/* place (or move) the index replica on a device; done implicitly on device 0 by the first query */
+/* place a replica of the index in the HBM of `device` (kept alongside replicas on other devices) and make it
+ * the one host-pointer entry points use; done implicitly on device 0 by the first query.  The *_device
+ * entry points run on the replica of whichever GPU owns the caller's buffers, uploading it on first use. */
 int mz_sshash_to_device(mz_sshash *ix, int device);
 
 /* K2U::k2u(&CanonicalKmer) -> Option<K2UPos>, sshash.rs:471-554.  k must equal the index's k

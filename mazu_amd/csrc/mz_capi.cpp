@@ -17,7 +17,8 @@ struct mz_unitig_set {
 
 struct mz_sshash {
     SSHashHost host;
-    DeviceIndex *dev = nullptr;
+    DeviceIndex *dev = nullptr;           // default replica (first one placed, or the last mz_sshash_to_device target)
+    std::vector<DeviceIndex *> replicas;  // one per device the index has been placed on (index replicated per GPU)
     std::mutex mu;
 };
 
@@ -36,10 +37,33 @@ struct mz_streaming {
         }                                                                                      \
     } while (0)
 
-static int ensure_device(mz_sshash *ix) {
+// replica on `device`, uploaded on first use; *out is owned by the handle
+static int replica_on(mz_sshash *ix, int device, DeviceIndex **out) {
     std::lock_guard<std::mutex> g(ix->mu);
+    for (DeviceIndex *r : ix->replicas)
+        if (r->device == device) { *out = r; return MZ_OK; }
+    DeviceIndex *nd = nullptr;
+    int rc = device_upload(ix->host, device, &nd);
+    if (rc != MZ_OK) return rc;
+    ix->replicas.push_back(nd);
+    if (!ix->dev) ix->dev = nd;
+    *out = nd;
+    return MZ_OK;
+}
+static int ensure_device(mz_sshash *ix) {
     if (ix->dev) return MZ_OK;
-    return device_upload(ix->host, 0, &ix->dev);
+    DeviceIndex *r;
+    return replica_on(ix, 0, &r);
+}
+// device-pointer entry points run on the replica of the GPU that owns the caller's buffer
+static int replica_for_pointer(mz_sshash *ix, const void *dptr, DeviceIndex **out) {
+    hipPointerAttribute_t attr;
+    if (dptr && hipPointerGetAttributes(&attr, dptr) == hipSuccess && attr.type == hipMemoryTypeDevice)
+        return replica_on(ix, attr.device, out);
+    (void)hipGetLastError(); // not a device pointer we can classify: fall back to the default replica
+    int rc = ensure_device(ix);
+    *out = ix->dev;
+    return rc;
 }
 
 extern "C" {
@@ -97,7 +121,7 @@ int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew
 }
 void mz_sshash_free(mz_sshash *ix) {
     if (!ix) return;
-    device_free(ix->dev);
+    for (DeviceIndex *r : ix->replicas) device_free(r);
     delete ix;
 }
 uint32_t mz_sshash_k(const mz_sshash *ix) { return ix->host.us.k; }
@@ -123,34 +147,33 @@ uint64_t mz_sshash_n_minimizers(const mz_sshash *ix) { return ix->host.n_minimiz
 uint64_t mz_sshash_n_minimizer_occs(const mz_sshash *ix) { return ix->host.pos.n; }
 uint64_t mz_sshash_n_kmers_in_skew_index(const mz_sshash *ix) { return ix->host.has_skew ? ix->host.skew_pos.n : 0; }
 uint64_t mz_sshash_num_bits(const mz_sshash *ix) { return ix->host.num_bits(); }
-uint64_t mz_sshash_device_bytes(const mz_sshash *ix) { return ix->dev ? ix->dev->bytes : 0; }
+uint64_t mz_sshash_device_bytes(const mz_sshash *ix) { return ix->dev ? ix->dev->bytes : 0; } /* per replica */
 
 int mz_sshash_to_device(mz_sshash *ix, int device) {
     if (!ix) { set_error("null index"); return MZ_EINVAL; }
-    std::lock_guard<std::mutex> g(ix->mu);
-    if (ix->dev && ix->dev->device == device) return MZ_OK;
-    DeviceIndex *nd = nullptr;
-    int rc = device_upload(ix->host, device, &nd);
+    DeviceIndex *r = nullptr;
+    int rc = replica_on(ix, device, &r);
     if (rc != MZ_OK) return rc;
-    device_free(ix->dev);
-    ix->dev = nd;
+    ix->dev = r; // host-pointer entry points use this replica from now on
     return MZ_OK;
 }
 
 int mz_sshash_k2u_batch_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
                                void *stream) {
     if (!ix || (n && (!d_fw_words || !d_out))) { set_error("null argument"); return MZ_EINVAL; }
-    int rc = ensure_device(ix);
+    DeviceIndex *r = nullptr;
+    int rc = replica_for_pointer(ix, d_out, &r);
     if (rc != MZ_OK) return rc;
-    return launch_k2u_batch(*ix->dev, d_fw_words, n, d_out, d_counts, (hipStream_t)stream);
+    return launch_k2u_batch(*r, d_fw_words, n, d_out, d_counts, (hipStream_t)stream);
 }
 
 int mz_sshash_k2u_batch_compact_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64_t n, uint64_t *d_hit_idx,
                                        mz_k2upos *d_hits, uint64_t *d_n_hits, void *stream) {
     if (!ix || !d_n_hits || (n && (!d_fw_words || !d_hit_idx || !d_hits))) { set_error("null argument"); return MZ_EINVAL; }
-    int rc = ensure_device(ix);
+    DeviceIndex *r = nullptr;
+    int rc = replica_for_pointer(ix, d_n_hits, &r);
     if (rc != MZ_OK) return rc;
-    return launch_k2u_compact(*ix->dev, d_fw_words, n, d_hit_idx, d_hits, d_n_hits, (hipStream_t)stream);
+    return launch_k2u_compact(*r, d_fw_words, n, d_hit_idx, d_hits, d_n_hits, (hipStream_t)stream);
 }
 
 int mz_sshash_k2u_batch(mz_sshash *ix, const uint64_t *fw_words, uint64_t n, mz_k2upos *out, mz_counts *counts) {
@@ -209,9 +232,10 @@ int mz_sshash_k2u_reads_device(mz_sshash *ix, const uint8_t *d_bases, uint64_t n
                                const uint64_t *d_kmer_offsets, uint64_t n_reads, int streaming, mz_k2upos *d_out,
                                mz_counts *d_counts, void *stream) {
     if (!ix || (n_reads && (!d_bases || !d_read_offsets || !d_kmer_offsets || !d_out))) { set_error("null argument"); return MZ_EINVAL; }
-    int rc = ensure_device(ix);
+    DeviceIndex *r = nullptr;
+    int rc = replica_for_pointer(ix, d_read_offsets, &r);
     if (rc != MZ_OK) return rc;
-    return launch_k2u_reads(*ix->dev, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, streaming, d_out, d_counts,
+    return launch_k2u_reads(*r, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, streaming, d_out, d_counts,
                             (hipStream_t)stream);
 }
 
@@ -298,9 +322,10 @@ int mz_sshash_validate_self(mz_sshash *ix, mz_validate_report *report) {
 int mz_sshash_extract_kmers_device(mz_sshash *ix, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
                                    uint64_t *d_fw_words, void *stream) {
     if (!ix || (n && (!d_positions || !d_fw_words))) { set_error("null argument"); return MZ_EINVAL; }
-    int rc = ensure_device(ix);
+    DeviceIndex *r = nullptr;
+    int rc = replica_for_pointer(ix, d_fw_words, &r);
     if (rc != MZ_OK) return rc;
-    return launch_extract_kmers(*ix->dev, d_positions, d_flip, n, d_fw_words, (hipStream_t)stream);
+    return launch_extract_kmers(*r, d_positions, d_flip, n, d_fw_words, (hipStream_t)stream);
 }
 
 int mz_sshash_save(const mz_sshash *ix, const char *path) {
