@@ -183,6 +183,33 @@ int mz_sshash_extract_kmers_device(mz_sshash *ix, const uint64_t *d_positions, c
 int mz_sshash_save(const mz_sshash *ix, const char *path);
 int mz_sshash_load(const char *path, mz_sshash **out);
 
+/* ------------------------------------------------------------ U2Pos projection ("next" row: the step after k2u) */
+/* MappedRefPos (src/index.rs:26-47) plus the index of the query it belongs to; o: 1 = Forward, 0 = Backward (lib.rs:50-64) */
+typedef struct mz_mapped_ref_pos {
+    uint32_t ref_id;
+    uint32_t pos;
+    uint32_t o;
+    uint32_t query;
+} mz_mapped_ref_pos;
+typedef struct mz_u2pos mz_u2pos; /* DenseUnitigTable as U2Pos, src/index/dense_unitig_table.rs:12-76 */
+/* ctable: pufferfish 64-bit occurrences [63]=fwd [62:32]=pos [31:0]=ref (index.rs:315-346); contig_offsets: n_unitigs+1 */
+int mz_u2pos_dense_new(const uint64_t *ctable, uint64_t n_occs, const uint64_t *contig_offsets, uint64_t n_unitigs, mz_u2pos **out);
+void mz_u2pos_free(mz_u2pos *u);
+uint64_t mz_u2pos_n_unitig_occs(const mz_u2pos *u, uint64_t ui); /* n_unitig_occs, dense_unitig_table.rs:69-71 */
+uint64_t mz_u2pos_num_total_occs(const mz_u2pos *u);             /* :34-36 */
+/* project_onto_u_occs (index.rs:184-216) for a batch of K2UPos records in HBM: d_offsets (n+1) receives the exclusive
+ * prefix sums of the per-query occurrence counts (d_offsets[n] = total), d_out (may be NULL to only count) the
+ * MappedRefPos records of query i at [d_offsets[i], d_offsets[i+1]); records beyond out_cap are not written. */
+int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets,
+                            mz_mapped_ref_pos *d_out, uint64_t out_cap, void *stream);
+/* the assertion of Validate::validate_self (index/validate.rs:24-52) for the k-mers 0..n of reference ref_id whose K2UPos
+ * records are d_recs: d_report[3] = {k-mers checked, failures, first failing position}, accumulated (init {0,0,~0}) */
+int mz_u2pos_check_refs_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint32_t ref_id, uint64_t *d_report,
+                               void *stream);
+/* GetRefPos::get_ref_pos_eager for a batch (index.rs:139-179), host buffers; *n_out = total records (may exceed out_cap) */
+int mz_get_ref_pos_batch(mz_sshash *ix, mz_u2pos *u, const uint64_t *fw_words, uint64_t n, uint64_t *hit_offsets,
+                         mz_mapped_ref_pos *out, uint64_t out_cap, uint64_t *n_out);
+
 /* ------------------------------------------------------------ StreamingK2U */
 /* SSHash::as_streaming(), sshash.rs:435-437 -> StreamingK2U::new, index/caching.rs:47-59 */
 int mz_streaming_new(mz_sshash *ix, mz_streaming **out);

@@ -87,6 +87,13 @@ def _load():
         "mz_sshash_extract_kmers_device": (i, [p, p, p, u64, p, p]),
         "mz_sshash_save": (i, [p, C.c_char_p]),
         "mz_sshash_load": (i, [C.c_char_p, p]),
+        "mz_u2pos_dense_new": (i, [p, u64, p, u64, p]),
+        "mz_u2pos_free": (None, [p]),
+        "mz_u2pos_n_unitig_occs": (u64, [p, u64]),
+        "mz_u2pos_num_total_occs": (u64, [p]),
+        "mz_u2pos_project_device": (i, [p, u32, p, u64, p, p, u64, p]),
+        "mz_u2pos_check_refs_device": (i, [p, u32, p, u64, u32, p, p]),
+        "mz_get_ref_pos_batch": (i, [p, p, p, u64, p, p, u64, p]),
         "mz_streaming_new": (i, [p, p]),
         "mz_streaming_free": (None, [p]),
         "mz_streaming_k2u": (i, [p, u64, u32, p]),

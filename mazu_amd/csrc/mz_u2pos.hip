@@ -1,0 +1,295 @@
+// mz_u2pos.hip -- the step right after k2u: unitig occurrences -> reference
+// positions on the device.  Mirrors reference src/index/dense_unitig_table.rs:55-76 (DenseUnitigTable as
+// U2Pos), src/index.rs:315-346 (pufferfish 64-bit occurrence codec) and src/index.rs:184-216
+// (project_onto_u_occ).  Variable-length output: count -> exclusive scan -> fill, all on the device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "mz_device.hpp"
+
+using namespace mz;
+
+struct mz_u2pos {
+    std::vector<uint64_t> ctable, offsets; // host copies (encoded_unitig_occs on the host side of the mirror)
+    uint64_t n_unitigs = 0;
+    int device = -1;
+    uint64_t *d_ctable = nullptr, *d_offsets = nullptr;
+};
+
+namespace {
+
+constexpr int kB = 256, kItems = 4, kTileN = kB * kItems;
+
+#define U2_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            set_error("HIP error %d (%s): %s", (int)_e, hipGetErrorString(_e), #expr);     \
+            return MZ_EHIP;                                                                \
+        }                                                                                  \
+    } while (0)
+
+// UnitigOcc::decode_pf1 (index.rs:334-346) + project_onto_u_occ (index.rs:184-216)
+__device__ __forceinline__ mz_mapped_ref_pos project(const mz_k2upos &r, uint64_t enc, uint32_t k, uint64_t query) {
+    const uint32_t ref_id = (uint32_t)(enc & 0xFFFFFFFFull);
+    const uint32_t pw = (uint32_t)(enc >> 32);
+    const uint32_t cpos = pw & 0x7FFFFFFFu;
+    const bool fwd = (pw & 0x80000000u) != 0;                         // Orientation::Forward
+    const uint32_t pos = fwd ? r.pos + cpos : cpos + (r.unitig_len - r.pos) - k;
+    uint32_t o = r.match == MZ_IDENTITY_MATCH ? 1u : 0u;             // Forward = 1, Backward = 0 (lib.rs:50-64)
+    if (!fwd) o = 1u - o;
+    return mz_mapped_ref_pos{ref_id, pos, o, (uint32_t)query};
+}
+
+__global__ __launch_bounds__(kB) void count_kernel(const mz_k2upos *__restrict__ recs, uint64_t n, const uint64_t *__restrict__ offsets,
+                                                   uint64_t n_unitigs, uint64_t *__restrict__ counts) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
+        mz_k2upos r = recs[i];
+        uint64_t c = 0;
+        if ((r.match == MZ_IDENTITY_MATCH || r.match == MZ_TWIN_MATCH) && r.unitig_id < n_unitigs)
+            c = offsets[r.unitig_id + 1] - offsets[r.unitig_id];
+        counts[i] = c;
+    }
+}
+
+// ---- exclusive scan of u64 counts (three small kernels; in place) ----
+__device__ __forceinline__ uint64_t block_exclusive(uint64_t v, uint64_t *total) {
+    __shared__ uint64_t wsum[kB / 64];
+    uint64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t o = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (int w = 0; w < kB / 64; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) base += wsum[w];
+        tot += wsum[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+__global__ __launch_bounds__(kB) void scan_tile_sums(const uint64_t *__restrict__ counts, uint64_t n, uint64_t *__restrict__ tile_sums) {
+    uint64_t base = (uint64_t)blockIdx.x * kTileN, s = 0;
+    for (int q = 0; q < kItems; ++q) {
+        uint64_t i = base + (uint64_t)threadIdx.x * kItems + q;
+        if (i < n) s += counts[i];
+    }
+    uint64_t tot;
+    block_exclusive(s, &tot);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(kB) void scan_tile_offsets(uint64_t *tile_sums, uint64_t n_tiles, uint64_t *grand_total) {
+    uint64_t carry = 0;
+    for (uint64_t b0 = 0; b0 < n_tiles; b0 += kB) { // one workgroup walks the tile sums
+        uint64_t i = b0 + threadIdx.x;
+        uint64_t v = i < n_tiles ? tile_sums[i] : 0, tot;
+        uint64_t ex = block_exclusive(v, &tot);
+        if (i < n_tiles) tile_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+__global__ __launch_bounds__(kB) void scan_apply(uint64_t *__restrict__ counts, uint64_t n, const uint64_t *__restrict__ tile_sums,
+                                                 const uint64_t *grand_total) {
+    uint64_t base = (uint64_t)blockIdx.x * kTileN;
+    uint64_t v[kItems], s = 0;
+    for (int q = 0; q < kItems; ++q) {
+        uint64_t i = base + (uint64_t)threadIdx.x * kItems + q;
+        v[q] = i < n ? counts[i] : 0;
+        s += v[q];
+    }
+    uint64_t tot;
+    uint64_t ex = block_exclusive(s, &tot) + tile_sums[blockIdx.x];
+    for (int q = 0; q < kItems; ++q) {
+        uint64_t i = base + (uint64_t)threadIdx.x * kItems + q;
+        if (i < n) counts[i] = ex;
+        ex += v[q];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts[n] = *grand_total; // offsets[n] = total
+}
+
+// fill: one lane per query for short lists; a query with >= 64 occurrences is walked by its whole wave
+__global__ __launch_bounds__(kB) void fill_kernel(const mz_k2upos *__restrict__ recs, uint64_t n, const uint64_t *__restrict__ table_off,
+                                                  const uint64_t *__restrict__ ctable, const uint64_t *__restrict__ out_off, uint32_t k,
+                                                  mz_mapped_ref_pos *__restrict__ out, uint64_t cap) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    uint64_t n_round = (n + 63) & ~63ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n_round; i += stride) {
+        mz_k2upos r = mz_k2upos{0, 0, 0, MZ_NO_MATCH};
+        uint64_t o0 = 0, c = 0, t0 = 0;
+        if (i < n) {
+            r = recs[i];
+            o0 = out_off[i];
+            c = out_off[i + 1] - o0;
+            if (c) t0 = table_off[r.unitig_id];
+        }
+        const bool longl = c >= 64;
+        if (c && !longl)
+            for (uint64_t j = 0; j < c; ++j)
+                if (o0 + j < cap) out[o0 + j] = project(r, ctable[t0 + j], k, i);
+        unsigned long long lb = __ballot(longl);
+        while (lb) { // wave-cooperative walk of the long lists of this wave's 64 queries
+            int src = __ffsll((long long)lb) - 1;
+            lb &= lb - 1;
+            mz_k2upos rr;
+            rr.unitig_id = __shfl(r.unitig_id, src); rr.pos = __shfl(r.pos, src);
+            rr.unitig_len = __shfl(r.unitig_len, src); rr.match = __shfl(r.match, src);
+            uint64_t so = __shfl(o0, src), sc = __shfl(c, src), st = __shfl(t0, src), sq = __shfl(i, src);
+            for (uint64_t j = __lane_id(); j < sc; j += 64)
+                if (so + j < cap) out[so + j] = project(rr, ctable[st + j], k, sq);
+        }
+    }
+}
+
+// Validate::validate_self (src/index/validate.rs:24-52) on the device: thread per reference k-mer; its k2u
+// record must project onto (ref_id, pos) through at least one occurrence of its unitig.
+__global__ __launch_bounds__(kB) void check_refs_kernel(const mz_k2upos *__restrict__ recs, uint64_t n, const uint64_t *__restrict__ table_off,
+                                                        const uint64_t *__restrict__ ctable, uint64_t n_unitigs, uint32_t k, uint32_t ref_id,
+                                                        unsigned long long *report /* n, n_fail, first_fail */) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    unsigned fails = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
+        mz_k2upos r = recs[i];
+        bool found = false;
+        if ((r.match == MZ_IDENTITY_MATCH || r.match == MZ_TWIN_MATCH) && r.unitig_id < n_unitigs) {
+            uint64_t a = table_off[r.unitig_id], b = table_off[r.unitig_id + 1];
+            for (uint64_t j = a; j < b && !found; ++j) {
+                mz_mapped_ref_pos m = project(r, ctable[j], k, i);
+                found = m.ref_id == ref_id && m.pos == (uint32_t)i;
+            }
+        }
+        if (!found) { ++fails; atomicMin(&report[2], (unsigned long long)i); }
+    }
+    for (int off = 32; off > 0; off >>= 1) fails += __shfl_down(fails, off);
+    if ((threadIdx.x & 63) == 0 && fails) atomicAdd(&report[1], (unsigned long long)fails);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&report[0], (unsigned long long)n);
+}
+
+unsigned grid_of(uint64_t n, unsigned cap = 256 * 16) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kB - 1) / kB, cap)); }
+
+int ensure_u2pos_device(mz_u2pos *u, int device) {
+    if (u->d_ctable && u->device == device) return MZ_OK;
+    if (device_count() <= 0) { set_error("no HIP device visible: projection runs on the GPU only"); return MZ_EHIP; }
+    U2_HIP(hipSetDevice(device));
+    if (u->d_ctable) { (void)hipFree(u->d_ctable); (void)hipFree(u->d_offsets); u->d_ctable = u->d_offsets = nullptr; }
+    U2_HIP(hipMalloc((void **)&u->d_ctable, std::max<size_t>(8, u->ctable.size() * 8)));
+    U2_HIP(hipMalloc((void **)&u->d_offsets, u->offsets.size() * 8));
+    if (!u->ctable.empty()) U2_HIP(hipMemcpy(u->d_ctable, u->ctable.data(), u->ctable.size() * 8, hipMemcpyHostToDevice));
+    U2_HIP(hipMemcpy(u->d_offsets, u->offsets.data(), u->offsets.size() * 8, hipMemcpyHostToDevice));
+    u->device = device;
+    return MZ_OK;
+}
+
+int device_of(const void *p) {
+    hipPointerAttribute_t a;
+    if (p && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeDevice) return a.device;
+    (void)hipGetLastError();
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int mz_u2pos_dense_new(const uint64_t *ctable, uint64_t n_occs, const uint64_t *contig_offsets, uint64_t n_unitigs, mz_u2pos **out) {
+    if (!out || !contig_offsets || (n_occs && !ctable)) { set_error("null argument"); return MZ_EINVAL; }
+    *out = nullptr;
+    for (uint64_t i = 0; i < n_unitigs; ++i)
+        if (contig_offsets[i + 1] < contig_offsets[i]) { set_error("contig offsets not monotone at %llu", (unsigned long long)i); return MZ_ENOTMONOTONE; }
+    if (contig_offsets[n_unitigs] > n_occs) { set_error("contig offsets exceed the occurrence table"); return MZ_EINVAL; }
+    mz_u2pos *u = new (std::nothrow) mz_u2pos();
+    if (!u) return MZ_ENOMEM;
+    u->ctable.assign(ctable, ctable + n_occs);
+    u->offsets.assign(contig_offsets, contig_offsets + n_unitigs + 1);
+    u->n_unitigs = n_unitigs;
+    *out = u;
+    return MZ_OK;
+}
+void mz_u2pos_free(mz_u2pos *u) {
+    if (!u) return;
+    if (u->d_ctable) { (void)hipFree(u->d_ctable); (void)hipFree(u->d_offsets); }
+    delete u;
+}
+uint64_t mz_u2pos_n_unitig_occs(const mz_u2pos *u, uint64_t ui) { return ui < u->n_unitigs ? u->offsets[ui + 1] - u->offsets[ui] : 0; }
+uint64_t mz_u2pos_num_total_occs(const mz_u2pos *u) { return u->ctable.size(); }
+
+int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets, mz_mapped_ref_pos *d_out,
+                            uint64_t out_cap, void *stream_) {
+    if (!u || !d_offsets || (n && !d_recs)) { set_error("null argument"); return MZ_EINVAL; }
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = ensure_u2pos_device(u, device_of(d_offsets));
+    if (rc != MZ_OK) return rc;
+    U2_HIP(hipSetDevice(u->device));
+    uint64_t n_tiles = (n + kTileN - 1) / kTileN;
+    uint64_t *d_tiles = nullptr;
+    U2_HIP(hipMallocAsync((void **)&d_tiles, (n_tiles + 2) * 8, stream));
+    if (n == 0) {
+        U2_HIP(hipMemsetAsync(d_offsets, 0, 8, stream));
+    } else {
+        hipLaunchKernelGGL(count_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->n_unitigs, d_offsets);
+        hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)n_tiles), dim3(kB), 0, stream, d_offsets, n, d_tiles);
+        hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(kB), 0, stream, d_tiles, n_tiles, d_tiles + n_tiles);
+        hipLaunchKernelGGL(scan_apply, dim3((unsigned)n_tiles), dim3(kB), 0, stream, d_offsets, n, d_tiles, d_tiles + n_tiles);
+        if (d_out && out_cap)
+            hipLaunchKernelGGL(fill_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->d_ctable, d_offsets, k, d_out, out_cap);
+    }
+    U2_HIP(hipGetLastError());
+    U2_HIP(hipFreeAsync(d_tiles, stream));
+    return MZ_OK;
+}
+
+int mz_u2pos_check_refs_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint32_t ref_id, uint64_t *d_report, void *stream_) {
+    if (!u || !d_report || (n && !d_recs)) { set_error("null argument"); return MZ_EINVAL; }
+    int rc = ensure_u2pos_device(u, device_of(d_report));
+    if (rc != MZ_OK) return rc;
+    U2_HIP(hipSetDevice(u->device));
+    hipLaunchKernelGGL(check_refs_kernel, dim3(grid_of(std::max<uint64_t>(n, 1))), dim3(kB), 0, (hipStream_t)stream_, d_recs, n, u->d_offsets,
+                       u->d_ctable, u->n_unitigs, k, ref_id, (unsigned long long *)d_report);
+    U2_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+// GetRefPos::get_ref_pos_eager for a batch (src/index.rs:139-179), host buffers: k2u on the GPU, projection on the GPU
+int mz_get_ref_pos_batch(mz_sshash *ix, mz_u2pos *u, const uint64_t *fw_words, uint64_t n, uint64_t *hit_offsets, mz_mapped_ref_pos *out,
+                         uint64_t out_cap, uint64_t *n_out) {
+    if (!ix || !u || !hit_offsets || !n_out || (n && !fw_words)) { set_error("null argument"); return MZ_EINVAL; }
+    *n_out = 0;
+    int rc = mz_sshash_to_device(ix, 0);
+    if (rc != MZ_OK) return rc;
+    const uint32_t k = mz_sshash_k(ix);
+    uint64_t *d_q = nullptr, *d_off = nullptr;
+    mz_k2upos *d_r = nullptr;
+    mz_mapped_ref_pos *d_o = nullptr;
+    U2_HIP(hipSetDevice(0));
+    auto cleanup = [&] { if (d_q) (void)hipFree(d_q); if (d_off) (void)hipFree(d_off); if (d_r) (void)hipFree(d_r); if (d_o) (void)hipFree(d_o); };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_q, std::max<uint64_t>(n, 1) * 8)) != hipSuccess || (e = hipMalloc((void **)&d_off, (n + 1) * 8)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_r, std::max<uint64_t>(n, 1) * sizeof(mz_k2upos))) != hipSuccess ||
+        (e = hipMalloc((void **)&d_o, std::max<uint64_t>(out_cap, 1) * sizeof(mz_mapped_ref_pos))) != hipSuccess) {
+        cleanup();
+        set_error("hipMalloc failed: %s", hipGetErrorString(e));
+        return MZ_ENOMEM;
+    }
+    rc = MZ_OK;
+    if (n && (e = hipMemcpy(d_q, fw_words, n * 8, hipMemcpyHostToDevice)) != hipSuccess) rc = MZ_EHIP;
+    if (rc == MZ_OK) rc = mz_sshash_k2u_batch_device(ix, d_q, n, d_r, nullptr, nullptr);
+    if (rc == MZ_OK) rc = mz_u2pos_project_device(u, k, d_r, n, d_off, out ? d_o : nullptr, out ? out_cap : 0, nullptr);
+    if (rc == MZ_OK && (e = hipMemcpy(hit_offsets, d_off, (n + 1) * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = MZ_EHIP;
+    if (rc == MZ_OK) {
+        *n_out = hit_offsets[n];
+        uint64_t m = std::min(*n_out, out_cap);
+        if (out && m && (e = hipMemcpy(out, d_o, m * sizeof(mz_mapped_ref_pos), hipMemcpyDeviceToHost)) != hipSuccess) rc = MZ_EHIP;
+    }
+    if (rc == MZ_EHIP && e != hipSuccess) set_error("HIP error in get_ref_pos_batch: %s", hipGetErrorString(e));
+    cleanup();
+    return rc;
+}
+
+} // extern "C"

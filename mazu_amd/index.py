@@ -5,6 +5,9 @@ it is given (mazu_amd.SSHash); occurrence projection stays on the host (numpy) -
 "next" row of SURVEY.md 8(f), not part of the accelerated path."""
 import numpy as np
 
+import ctypes as C
+
+from ._capi import check, lib
 from .kphf import CanonicalKmer, MatchType
 from . import pf1
 
@@ -27,11 +30,32 @@ class MappedRefPos:  # src/index.rs:26-47
     def __repr__(self): return f"MappedRefPos(ref_id={self.ref_id}, pos={self.pos}, o={'fw' if self.o else 'rc'})"
 
 
+MAPPED_DTYPE = np.dtype([("ref_id", "<u4"), ("pos", "<u4"), ("o", "<u4"), ("query", "<u4")])
+
+
 class DenseUnitigTable:  # src/index/dense_unitig_table.rs:12-76 (U2Pos)
     def __init__(self, ctable, contig_offsets, ref_names):
-        self.ctable = np.asarray(ctable, dtype=np.uint64)
-        self.contig_offsets = np.asarray(contig_offsets, dtype=np.uint64)
+        self.ctable = np.ascontiguousarray(ctable, dtype=np.uint64)
+        self.contig_offsets = np.ascontiguousarray(contig_offsets, dtype=np.uint64)
         self.ref_names = list(ref_names)
+        self._h = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.mz_u2pos_free(self._h)
+            self._h = None
+
+    def handle(self):
+        """device-backed twin (mz_u2pos) for the projection kernels; created on first use"""
+        if self._h is None:
+            h = C.c_void_p()
+            check(lib.mz_u2pos_dense_new(self.ctable.ctypes.data, len(self.ctable), self.contig_offsets.ctypes.data,
+                                         len(self.contig_offsets) - 1, C.byref(h)))
+            self._h = h
+        return self._h
+
+    def n_unitig_occs(self, ui): return lib.mz_u2pos_n_unitig_occs(self.handle(), ui)
+    def num_total_occs(self): return lib.mz_u2pos_num_total_occs(self.handle())
 
     def encoded_unitig_occs(self, ui):
         return self.ctable[int(self.contig_offsets[ui]): int(self.contig_offsets[ui + 1])]
@@ -137,6 +161,43 @@ class ModIndex:  # src/index.rs:49-124
 
     def as_streaming(self):  # src/index/caching.rs:221-232
         return StreamingIndex(self)
+
+    # ---- device-resident forms (k2u AND the projection on the GPU)
+    def get_ref_pos_batch(self, fw_words, cap=None):
+        """get_ref_pos_eager for a batch: returns (offsets[n+1], MappedRefPos records grouped by query)"""
+        fw = np.ascontiguousarray(fw_words, dtype=np.uint64)
+        offs = np.zeros(len(fw) + 1, dtype=np.uint64)
+        cap = int(cap if cap is not None else max(16, 4 * len(fw)))
+        while True:
+            out = np.zeros(cap, dtype=MAPPED_DTYPE)
+            n_out = C.c_uint64(0)
+            check(lib.mz_get_ref_pos_batch(self.k2u._h, self.u2pos.handle(), fw.ctypes.data, len(fw), offs.ctypes.data,
+                                           out.ctypes.data, cap, C.byref(n_out)))
+            if n_out.value <= cap:
+                return offs, out[: n_out.value]
+            cap = int(n_out.value)
+
+    def validate_self_on_device(self):
+        """Validate::validate_self (src/index/validate.rs:24-52) with lookup, projection and the assertion all
+        on the device; returns the number of k-mers checked, raises where the reference would panic"""
+        import torch
+        assert self.refs.has_seq()
+        dev = torch.device("cuda", 0)
+        report = torch.tensor([0, 0, -1], dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for r in range(self.refs.n_refs()):
+            fw = self.refs.kmer_words(r, self.k())
+            if len(fw) == 0:
+                continue
+            dq = torch.from_numpy(fw.view(np.int64)).to(dev)
+            drec = torch.empty(2 * len(fw), dtype=torch.int64, device=dev)
+            self.k2u.k2u_batch_device(dq, drec, None, stream)
+            check(lib.mz_u2pos_check_refs_device(self.u2pos.handle(), self.k(), drec.data_ptr(), len(fw), r, report.data_ptr(), stream))
+        torch.cuda.synchronize(dev)
+        n, n_fail, first = report.cpu().tolist()
+        if n_fail:
+            raise AssertionError(f"No matching MRP for {n_fail} true +ve k-mers (first at position {first})")
+        return n
 
 
 class StreamingIndex:  # src/index/caching.rs:37-41,141-219

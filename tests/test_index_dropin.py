@@ -113,3 +113,28 @@ def test_streaming_validate_fasta_piscem_style():  # caching.rs:238-253 / piscem
             bases = np.frombuffer(seq.encode(), dtype=np.uint8)
             recs, counts = ix.k2u_reads(bases, np.array([0, len(bases)], dtype=np.uint64), streaming=True)
             assert counts[1] == 0 and counts[0] + counts[2] == len(recs) and counts[0] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,skew", [("tiny-multi-refs/tiny-multi-refs_index", 3, 0), ("small_txome_index", 15, 32), ("yeast_chr01_index", 15, 32)])
+def test_projection_on_device_matches_host_projection(name, w, skew):  # index.rs:184-216, dense_unitig_table.rs:55-76
+    idx, f = I.dense_index_from_pf1(os.path.join(PF1, name), gpu_factory(w, skew))
+    n_dev = idx.validate_self_on_device()               # lookup + projection + assertion on the GPU
+    assert n_dev == idx.validate_self()                 # host projection of the same GPU lookups
+    # record-level parity of get_ref_pos_batch with the host mirror of project_onto_u_occs, incl. misses
+    rng = np.random.default_rng(4)
+    fw = np.concatenate([idx.refs.kmer_words(r, f.k)[:: max(1, idx.refs.ref_len(r) // 4000)] for r in range(idx.refs.n_refs())])
+    fw = np.concatenate([fw, H.rc_words(fw[::3], f.k), rng.integers(0, 1 << (2 * f.k), 500, dtype=np.uint64)])
+    offs, recs = idx.get_ref_pos_batch(fw, cap=8)       # tiny cap: exercises the grow-and-retry path
+    k2u_recs, _ = idx.k2u.k2u_batch(fw)
+    assert len(offs) == len(fw) + 1 and int(offs[-1]) == len(recs)
+    for i in rng.integers(0, len(fw), 300):
+        got = recs[int(offs[i]): int(offs[i + 1])]
+        if int(k2u_recs[i]["match"]) == 0:
+            assert len(got) == 0
+            continue
+        ref_id, cpos, fwd = I.DenseUnitigTable.decode_pf1(idx.u2pos.encoded_unitig_occs(int(k2u_recs[i]["unitig_id"])))
+        want = I.project_onto_u_occs(f.k, k2u_recs[i], ref_id, cpos, fwd)
+        assert [(int(g["ref_id"]), int(g["pos"]), int(g["o"])) for g in got] == [(m.ref_id, m.pos, m.o) for m in want]
+        assert (got["query"] == i).all()
+    assert idx.u2pos.num_total_occs() == len(f.ctable)
