@@ -144,11 +144,14 @@ def main():
     n_gpus = world
     if M.lib.mz_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the k2u path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; MZ_DIST_BACKEND=gloo lets several ranks share one card to rehearse the N>1 path on a 1-GPU box
+    backend = os.environ.get("MZ_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     from mazu_amd import dist as D
-    D.init("nccl", dev)  # nccl == RCCL on ROCm; no-op for a single process
+    D.init(backend, dev)  # nccl == RCCL on ROCm; no-op for a single process
 
     k = 31
     batch = args.batch or DEFAULT_BATCH[args.workload]
@@ -177,7 +180,7 @@ def main():
             os.unlink(shared)
     t_build = time.time() - t0
     t0 = time.time()
-    ix.to_device(local_rank)
+    ix.to_device(dev_index)
     torch.cuda.synchronize(dev)
     t_upload = time.time() - t0
     log(f"{args.workload}: {us['total_len']} bp, {us['n_unitigs']} unitigs, {ix.n_kmers()} k-mers; gen {t_gen:.1f}s "

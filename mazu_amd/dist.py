@@ -32,17 +32,32 @@ def shard_reads(read_offsets, rank, world):
     return shard_bounds(len(read_offsets) - 1, rank, world)
 
 
+def _active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _reduce(t, op):
+    """all_reduce that also works when the backend is gloo and the tensor lives in HBM (CPU rehearsals)"""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def allreduce_counts(counts):
     """sum a 3-element int64 tensor {n_hit, n_miss, n_skipped} over all ranks (in place)"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    if _active():
+        _reduce(counts, dist.ReduceOp.SUM)
     return counts
 
 
 def max_over_ranks(seconds, device="cpu"):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        t = torch.tensor([seconds], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if _active():
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+        _reduce(t, dist.ReduceOp.MAX)
         return float(t.item())
     return seconds
 
