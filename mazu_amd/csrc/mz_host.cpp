@@ -614,6 +614,11 @@ static void scan_unitig(const uint64_t *useq, uint64_t s, uint64_t e, uint32_t k
 
 int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads) {
     double t0 = now_s();
+    const bool timing = std::getenv("MZ_BUILD_TIMING") != nullptr;
+    double tp = t0;
+    auto phase = [&](const char *name) {
+        if (timing) { double t = now_s(); std::fprintf(stderr, "[mz build] %-28s %7.2f s\n", name, t - tp); tp = t; }
+    };
     if (n_threads <= 0) n_threads = hw_threads();
     if (w_ == 0 || w_ > unitigs.k) { // assert!(w <= unitigs.k()), sshash.rs:92
         set_error("SSHash: minimizer size w=%u must be in 1..=k (k=%u)", w_, unitigs.k);
@@ -627,6 +632,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     const uint32_t k = us.k;
     const uint64_t *useq = us.useq.data();
 
+    phase("copy unitig set");
     // 1. collect minimizer occurrences (sshash.rs:94-143), unitigs sharded over threads by bases
     int nt = n_threads;
     std::vector<std::vector<Occ>> parts(nt);
@@ -660,6 +666,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
         set_error("SSHash: no k-mers (every unitig shorter than k=%u)", k);
         return MZ_EEMPTY;
     }
+    phase("scan minimizers");
     // 2. sort by (word,pos), drop exact duplicates, run-length -> minimizer set (sshash.rs:145-172)
     sort_occs(occs, 2 * w, nt);
     occs.erase(std::unique(occs.begin(), occs.end(), [](const Occ &a, const Occ &b) { return a.word == b.word && a.pos == b.pos; }),
@@ -674,6 +681,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     uint64_t n_mm = mm_set.size();
     range.push_back(n_occ);
     n_minimizers = n_mm;
+    phase("sort + dedup + run-length");
     // 3. MPHF over the minimizer set, gamma = 1.7 (sshash.rs:177)
     // 2w <= 32: direct-address monotone MPHF (one line per probe, exact membership); else BBHash levels
     //   (only while the records stay small next to the key set: at most max(64 MiB, 16 B per key))
@@ -684,22 +692,25 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     }
     int rc = use_direct ? mm.build_direct(mm_set.data(), n_mm, 2 * w, nt) : mm.build(mm_set.data(), n_mm, 1.7, nt);
     if (rc != MZ_OK) return rc;
+    phase("minimizer mphf");
     // 4. bucket sizes in hash order -> prefix sums (sshash.rs:179-189)
     std::vector<uint64_t> slot(n_mm), psum(n_mm + 1, 0);
     {
         MphfView mv = mm.view();
         uint64_t *S = slot.data(), *P = psum.data();
         const uint64_t *M = mm_set.data(), *R = range.data();
+        const bool monotone = mm.direct != 0; // direct mode: bucket id == rank of the word == index in the sorted set
         parallel_for(nt, n_mm, [=](int, uint64_t b, uint64_t e) {
             for (uint64_t i = b; i < e; ++i) {
-                uint64_t h = 0;
-                mphf_lookup(mv, M[i], h);
+                uint64_t h = i;
+                if (!monotone) mphf_lookup(mv, M[i], h);
                 S[i] = h;
                 P[h + 1] = R[i + 1] - R[i];
             }
         });
         for (uint64_t i = 0; i < n_mm; ++i) psum[i + 1] += psum[i];
     }
+    phase("bucket sizes + prefix");
     // 5. scatter positions into their buckets (sshash.rs:191-219)
     std::vector<uint64_t> posv(n_occ);
     uint64_t max_pos = 0;
@@ -717,6 +728,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
         });
         max_pos = make_entry(us.total_len, 1, 0xFFFF);
     }
+    phase("scatter + flanks");
     // 6. skew index (sshash.rs:221-296): k-mers around every occurrence of a heavy minimizer
     if (skew_param != ~0ull) {
         std::vector<std::vector<Occ>> sparts(nt);
@@ -769,11 +781,13 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
         skew_pos.assign(spos.data(), sn, us.total_len, nt);
         has_skew = true;
     }
+    phase("skew index");
     // 7. finish (sshash.rs:310-329): Elias-Fano the prefix sums, bit-pack the positions
     rc = buckets.build(psum.data(), n_mm + 1, nt);
     if (rc != MZ_OK) return rc;
     if (mm.direct) n_minrec_overflow = mm.fill_bucket_offsets(psum.data(), n_mm + 1, nt);
     pos.assign(posv.data(), n_occ, max_pos, nt);
+    phase("EF + minrec + pack");
     build_seconds = now_s() - t0;
     return MZ_OK;
 }
