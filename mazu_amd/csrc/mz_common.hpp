@@ -286,8 +286,8 @@ struct IndexView {
     uint64_t total_len;
     uint64_t n_unitigs;
     uint64_t skew_param;
-    const uint64_t *useq;      // 2-bit packed unitig concatenation (+2 pad words)
-    const uint64_t *bv_blocks; // boundary blocks, 8 words per 256 bases
+    const uint64_t *seqbv;     // 128-byte records: words 0..7 = 256 bases of the 2-bit packed unitig concatenation,
+                               // words 8..15 = the boundary block of the same 256 bases (verify + locate share ONE line)
     MphfView mm;               // minimizer -> bucket id
     BefView buckets;           // bucket id -> [start,end) in pos  (occs_prefix_sum, partitioned Elias-Fano)
     const uint64_t *pos;       // packed entries: (minimizer position << 17) | (strand class << 16) | flank16
@@ -410,10 +410,12 @@ MZ_HD uint64_t ef_get(const EfView &e, uint64_t i) {
 struct UnitigSpan {
     uint64_t id, start, end;
 };
+MZ_HD UnitigSpan locate_unitig(const uint64_t *b, uint32_t off, uint64_t base);
 MZ_HD UnitigSpan locate_unitig(const uint64_t *bv_blocks, uint64_t pos) {
-    const uint64_t *b = bv_blocks + (pos >> kBvBasesPerBlockLog2) * 8;
-    uint32_t off = (uint32_t)(pos & (kBvBasesPerBlock - 1));
-    uint64_t base = pos & ~(uint64_t)(kBvBasesPerBlock - 1);
+    return locate_unitig(bv_blocks + (pos >> kBvBasesPerBlockLog2) * 8, (uint32_t)(pos & (kBvBasesPerBlock - 1)),
+                         pos & ~(uint64_t)(kBvBasesPerBlock - 1));
+}
+MZ_HD UnitigSpan locate_unitig(const uint64_t *b, uint32_t off, uint64_t base) {
     uint64_t id0 = b[0], start0 = b[1], end_last = b[2];
     uint64_t d[4] = {b[4], b[5], b[6], b[7]};
     uint32_t wsel = off >> 6, bi = off & 63;
@@ -436,6 +438,21 @@ MZ_HD UnitigSpan locate_unitig(const uint64_t *bv_blocks, uint64_t pos) {
     return s;
 }
 
+
+// ---- interleaved sequence / boundary records (IndexView::seqbv) ----------------------------------------
+constexpr uint32_t kSeqRecWords = 16;
+MZ_HD uint64_t seq_word_i(const uint64_t *rec, uint64_t wi) { return rec[(wi >> 3) * kSeqRecWords + (wi & 7)]; }
+MZ_HD uint64_t read_kmer_i(const uint64_t *rec, uint64_t pos, uint32_t k) {
+    uint64_t b = pos * 2, wi = b >> 6;
+    uint32_t sh = (uint32_t)(b & 63);
+    uint64_t lo = seq_word_i(rec, wi), hi = seq_word_i(rec, wi + 1);
+    uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    return x & kmer_mask(k);
+}
+MZ_HD UnitigSpan locate_unitig_i(const uint64_t *rec, uint64_t pos) {
+    return locate_unitig(rec + (pos >> kBvBasesPerBlockLog2) * kSeqRecWords + 8, (uint32_t)(pos & (kBvBasesPerBlock - 1)),
+                         pos & ~(uint64_t)(kBvBasesPerBlock - 1));
+}
 
 // ---- `pos` entry: (minimizer position << 17) | (strand class << 16) | flank16 ---------------------
 // flank16 = the 4 bases left of the minimizer occurrence (low byte; base pos-4 in the low bits) and
@@ -489,9 +506,9 @@ MZ_HD mz_k2upos skew_lookup(const IndexView &ix, uint64_t fw, uint64_t rc) {
     uint64_t word = fw < rc ? fw : rc, h;
     if (!mphf_lookup(ix.skew, word, h)) return make_none();
     uint64_t p = read_packed(ix.skew_pos, h, ix.skew_pos_width);
-    uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, ix.k));
+    uint32_t mt = word_equivalency(fw, rc, read_kmer_i(ix.seqbv, p, ix.k));
     if (mt == MZ_NO_MATCH) return make_none();
-    return make_hit(locate_unitig(ix.bv_blocks, p), p, mt);
+    return make_hit(locate_unitig_i(ix.seqbv, p), p, mt);
 }
 
 // sshash.rs:478-554 once the canonical minimizer is known
@@ -520,9 +537,9 @@ MZ_HD mz_k2upos lookup_with_minimizer(const IndexView &ix, uint64_t fw, uint64_t
         if (!flank_ok(X, (uint32_t)off, k, w, (uint32_t)(ent & 0xFFFFu))) continue;
         if (mm_pos >= off && mm_pos - off <= last_km_start) {
             uint64_t p = mm_pos - off;
-            uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
+            uint32_t mt = word_equivalency(fw, rc, read_kmer_i(ix.seqbv, p, k));
             if (mt != MZ_NO_MATCH) {
-                UnitigSpan s = locate_unitig(ix.bv_blocks, p);
+                UnitigSpan s = locate_unitig_i(ix.seqbv, p);
                 if (p + k <= s.end) return make_hit(s, p, mt);     // :509-514, :538-541
             }
         }

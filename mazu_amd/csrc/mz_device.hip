@@ -339,7 +339,7 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
                 cand[a] = e0 + a * kBlock < E && flank_ok(X, (uint32_t)off, k, w, (uint32_t)(ent[a] & 0xFFFFu)) && mm_pos >= off &&
                           mm_pos - off <= last_km_start;
                 pp[a] = mm_pos - off;
-                kw[a] = cand[a] ? read_kmer(ix.useq, pp[a], k) : 0;
+                kw[a] = cand[a] ? read_kmer_i(ix.seqbv, pp[a], k) : 0;
             }
 #pragma unroll
             for (int a = 0; a < kEpt; ++a) {
@@ -375,7 +375,7 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
                 if (S.n[i] == kNMiss) continue;
                 uint64_t p = read_packed(ix.skew_pos, S.slot[i], ix.skew_pos_width);
                 uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                uint32_t mt = word_equivalency(fw, rc, read_kmer(ix.useq, p, k));
+                uint32_t mt = word_equivalency(fw, rc, read_kmer_i(ix.seqbv, p, k));
                 if (mt != MZ_NO_MATCH) S.best[i] = ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p;
             }
         }
@@ -388,7 +388,7 @@ __device__ __forceinline__ mz_k2upos tile_result(const TileLds &S, const IndexVi
     unsigned long long b = S.best[i];
     if (b == kBestNone) return make_none();
     uint64_t p = b & ((1ull << kPosBits) - 1);
-    UnitigSpan s = locate_unitig(ix.bv_blocks, p);
+    UnitigSpan s = locate_unitig_i(ix.seqbv, p);
     if (p + ix.k <= s.end) return make_hit(s, p, ((b >> kPosBits) & 1) ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH);
     return lookup(ix, S.fw[i]); // first verified candidate straddles two unitigs (sshash.rs:509-514): exact in-order rescan
 }
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, uns
                 while (ix.starts[u + 1] <= p) ++u;
                 ui[q] = u; us[q] = ix.starts[u]; ue[q] = ix.starts[u + 1];
                 valid[q] = p + k <= ue[q];
-                if (valid[q]) { fw = read_kmer(ix.useq, p, k); rc = kmer_rc(fw, k); }
+                if (valid[q]) { fw = read_kmer_i(ix.seqbv, p, k); rc = kmer_rc(fw, k); }
             }
             Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
             tile_set_query(S, i, fw, mn, valid[q]);          // km
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, uns
                     if (r.match != MZ_NO_MATCH && r.unitig_id < ix.n_unitigs) {
                         uint64_t at = ix.starts[r.unitig_id] + r.pos;
                         if (at + k <= ix.total_len && at != p) {
-                            uint64_t kw = read_kmer(ix.useq, at, k), fw = S.fw[i];
+                            uint64_t kw = read_kmer_i(ix.seqbv, at, k), fw = S.fw[i];
                             dup = kw == fw || kw == kmer_rc(fw, k);
                         }
                     }
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void extract_kmers_kernel(IndexView ix, con
     uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         uint64_t p = positions[i];
-        uint64_t x = p + ix.k <= ix.total_len ? read_kmer(ix.useq, p, ix.k) : 0;
+        uint64_t x = p + ix.k <= ix.total_len ? read_kmer_i(ix.seqbv, p, ix.k) : 0;
         fw_words[i] = (flip && flip[i]) ? kmer_rc(x, ix.k) : x;
     }
 }
@@ -790,8 +790,7 @@ int device_upload(const SSHashHost &h, int device, DeviceIndex **out) {
     IndexView v = h.view();
     int rc = MZ_OK;
     auto fail = [&](int code) { device_free(d); return code; };
-    if ((rc = upload(d, h.us.useq.data(), h.us.useq.size(), &v.useq)) != MZ_OK) return fail(rc);
-    if ((rc = upload(d, h.us.bv_blocks.data(), h.us.bv_blocks.size(), &v.bv_blocks)) != MZ_OK) return fail(rc);
+    if ((rc = upload(d, h.us.seqbv.data(), h.us.seqbv.size(), &v.seqbv)) != MZ_OK) return fail(rc);
     if ((rc = upload(d, h.us.starts.data(), h.us.starts.size(), &v.starts)) != MZ_OK) return fail(rc);
     if ((rc = upload_mphf(d, h.mm, &v.mm)) != MZ_OK) return fail(rc);
     if ((rc = upload(d, h.buckets.blocks.data(), h.buckets.blocks.size(), &v.buckets.blocks)) != MZ_OK) return fail(rc);

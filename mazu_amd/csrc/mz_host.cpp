@@ -423,7 +423,18 @@ int UnitigSet::finish() {
         bv_blocks[b * 8 + 1] = starts[uid];
         bv_blocks[b * 8 + 2] = starts[ul + 1];
     }
+    build_seqbv();
     return MZ_OK;
+}
+
+// interleave the packed sequence and the boundary blocks into 128-byte records (IndexView::seqbv)
+void UnitigSet::build_seqbv() {
+    uint64_t nb = bv_blocks.size() / 8, nw = useq.size();
+    uint64_t nr = std::max<uint64_t>(nb, (nw + 7) / 8) + 1;
+    seqbv.assign(nr * kSeqRecWords, 0);
+    for (uint64_t wi = 0; wi < nw; ++wi) seqbv[(wi >> 3) * kSeqRecWords + (wi & 7)] = useq[wi];
+    for (uint64_t b = 0; b < nb; ++b)
+        for (int q = 0; q < 8; ++q) seqbv[b * kSeqRecWords + 8 + q] = bv_blocks[b * 8 + q];
 }
 
 int UnitigSet::from_packed(const uint64_t *words, uint64_t total_len_, const uint64_t *starts_, uint64_t n, uint32_t k_) {
@@ -800,8 +811,7 @@ IndexView SSHashHost::view() const {
     v.total_len = us.total_len;
     v.n_unitigs = us.n_unitigs;
     v.skew_param = skew_param;
-    v.useq = us.useq.data();
-    v.bv_blocks = us.bv_blocks.data();
+    v.seqbv = us.seqbv.data();
     v.mm = mm.view();
     v.buckets = buckets.view();
     v.pos = pos.w.data();
@@ -878,6 +888,7 @@ int SSHashHost::load(const std::string &path) {
               get_ef(f, us.accum_lens) && get_mphf(f, mm) && get(f, buckets.n) && get(f, buckets.n_overflow) && getv(f, buckets.blocks) && getv(f, buckets.ovf) && get_pv(f, pos);
     has_skew = hs != 0;
     if (ok && has_skew) ok = get_mphf(f, skew) && get_pv(f, skew_pos);
+    if (ok) us.build_seqbv();
     if (!ok) {
         set_error("%s: truncated", path.c_str());
         return MZ_EIO;

@@ -33,7 +33,7 @@ int main(int argc, char **argv) {
             uint64_t s = us.starts[ui], e = us.starts[ui + 1];
             if (us.unitig_len(ui) != e - s || us.unitig_start_pos(ui) != s) ++fails;
             for (uint64_t p = s; p + k <= e; ++p, ++n) {
-                uint64_t fw = read_kmer(v.useq, p, k);
+                uint64_t fw = read_kmer_i(v.seqbv, p, k);
                 mz_k2upos r = lookup(v, fw);
                 if (!(r.match == MZ_IDENTITY_MATCH && r.unitig_id == ui && r.pos == p - s && r.unitig_len == e - s)) ++fails;
                 r = lookup(v, kmer_rc(fw, k));
