@@ -596,7 +596,9 @@ orc_index *orc_build(const uint64_t *useq_words, uint64_t total_len, const uint6
 
     /* brute-force dictionary: every valid k-mer position, keyed by canonical word */
     if (with_dict) {
-        uint64_t nk = us_n_kmers(us), j = 0;
+        /* counted, not us_n_kmers(): the reference formula (unitig_set.rs:212-214) assumes every unitig holds >= k bases */
+        uint64_t nk = 0, j = 0;
+        for (uint64_t ui = 0; ui < n_unitigs; ++ui) if (starts[ui + 1] - starts[ui] >= k) nk += starts[ui + 1] - starts[ui] - k + 1;
         wp_pair *d = (wp_pair *)malloc((nk ? nk : 1) * sizeof *d);
         for (uint64_t ui = 0; ui < n_unitigs; ++ui)
             for (uint64_t p = starts[ui]; p + k <= starts[ui + 1]; ++p) {

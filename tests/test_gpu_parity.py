@@ -311,3 +311,48 @@ def test_synthetic_s_yeast_scale_properties():
     qs = q[:200000].cpu().numpy().view(np.uint64)
     want, _ = orc.k2u_batch(qs, n_threads=8)
     assert out[:400000].cpu().numpy().view(M.K2UPOS_DTYPE).tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 1023, 1024, 1025, 4097])
+def test_batch_sizes_around_tile_boundaries(yeast, n):
+    k, seqs = yeast
+    ix, orc, (words, total, starts) = both(seqs, k, 15, 16)
+    q = H.query_mix(words, starts, k, n, seed=n)
+    got, counts = ix.k2u_batch(q)
+    want, n_hit = orc.k2u_batch(q)
+    assert got.tobytes() == want.tobytes() and counts == (n_hit, n - n_hit, 0)
+
+
+def test_degenerate_unitig_sets():
+    """unitigs shorter than k (hold no k-mer), exactly k long, one single unitig, w == k"""
+    rng = np.random.default_rng(12)
+    def rnd(n): return "".join("ACGT"[int(c)] for c in rng.integers(0, 4, n))
+    seqs = [rnd(31), rnd(5), rnd(400), rnd(30), rnd(31), rnd(1), rnd(1200), rnd(64)]
+    for w, skew in ((15, M.MZ_NO_SKEW_INDEX), (31, M.MZ_NO_SKEW_INDEX), (8, 1), (19, 0)):
+        ix, orc, (words, total, starts) = both(seqs, 31, w, skew)
+        assert ix.n_kmers() == orc.n_kmers()  # n_kmers counts per the formula of unitig_set.rs:212-214
+        q = H.query_mix(words, starts, 31, 5000, seed=w)
+        # every k-mer start position in the concatenation, incl. the ones straddling two unitigs
+        allpos = np.arange(0, total - 31 + 1)
+        q = np.concatenate([q, H.kmer_words_at(words, allpos, 31)])
+        got, _ = ix.k2u_batch(q)
+        truth, _ = orc.k2u_batch(q, use_dict=True)
+        want, _ = orc.k2u_batch(q)
+        assert want.tobytes() == truth.tobytes() and got.tobytes() == want.tobytes()
+    one = [rnd(5000)]
+    ix, orc, (words, total, starts) = both(one, 21, 11, 4)
+    rep = ix.validate_self_report()
+    assert rep["n_fail"] == 0 and rep["n_kmers"] == 5000 - 21 + 1
+
+
+def test_reads_edge_shapes(yeast):
+    """reads exactly k long, k-1 long, empty, all-N, and a batch whose bases end exactly on a tile boundary"""
+    k, seqs = yeast
+    ix, orc, _ = both(seqs, k, 15, 16)
+    ref = H.read_fasta(CF_YEAST + ".fa")[0][1]
+    reads = [ref[100:100 + k], ref[200:200 + k - 1], "", "N" * 40, ref[1000:1000 + 1024 - (k + k - 1 + 40)], ref[5000:5000 + 2048]]
+    bases, ro = reads_fixture([("", r) for r in reads])
+    got, counts = ix.k2u_reads(bases, ro, streaming=True)
+    want, ko, oc = orc.k2u_reads(bases, ro, streaming=True)
+    assert got.tobytes() == want.tobytes() and list(counts) == oc.tolist()
+    assert counts[2] == 40 - k + 1
