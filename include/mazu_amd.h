@@ -115,6 +115,11 @@ const uint64_t *mz_unitig_set_useq_words(const mz_unitig_set *us);
  * README.md:22).  n_threads <= 0 uses every host core. */
 int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed,
                               int n_threads, mz_sshash **out);
+/* same construction with the heavy steps on the GPU `device` (minimizer scan with the window staged in LDS, radix sort,
+ * minimizer records, Elias-Fano, packed entries, skew MPHF): bit-identical arrays to the host builder.  Configurations it
+ * does not cover (w > 16, or an occurrence not fitting one 64-bit sort key) are built on the host transparently. */
+int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int device,
+                                     mz_sshash **out);
 void mz_sshash_free(mz_sshash *ix);
 
 /* trait K2U accessors, kphf/mod.rs:58-67 (impl at sshash.rs:446-469) */

@@ -60,6 +60,7 @@ def _load():
         "mz_unitig_set_pos_to_id": (u64, [p, u64]),
         "mz_unitig_set_useq_words": (p, [p]),
         "mz_sshash_from_unitig_set": (i, [p, u32, u64, u64, i, p]),
+        "mz_sshash_from_unitig_set_device": (i, [p, u32, u64, u64, i, p]),
         "mz_sshash_free": (None, [p]),
         "mz_sshash_k": (u32, [p]),
         "mz_sshash_n_kmers": (u64, [p]),

@@ -1,0 +1,579 @@
+// mz_build_gpu.hip -- index construction on the device.
+//
+// Produces, array for array and bit for bit, what SSHashHost::build (mz_host.cpp, the restatement of
+// reference src/kphf/sshash.rs:86-329 in this repository's layout) produces on the host:
+//   G1  minimizer occurrences of every k-mer (sliding-window minimizer, w-mer hashes staged in LDS), one
+//       64-bit key (word | position | strand class) per run of equal keys, wave-ballot compacted
+//   G2  radix sort + unique (rocPRIM device primitives), run-length -> minimizer set, bucket sizes,
+//       exclusive scan -> bucket starts
+//   G3  minimizer records (membership bitmap, ranks, per-record Elias-Fano halves), global partitioned
+//       Elias-Fano, packed `pos` entries with strand class and flank fingerprint
+//   G4  skew index: k-mers around heavy minimizers, sort/unique, BBHash levels built with atomics
+// Restrictions (otherwise the caller falls back to the host builder): direct-address minimizer records
+// (2w <= 32) and 2w + bit_len(total_len) + 1 <= 64 so that an occurrence fits one 64-bit sort key.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "mz_device.hpp"
+
+namespace mz {
+
+#define BG_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            set_error("HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+            return MZ_EHIP;                                                                           \
+        }                                                                                             \
+    } while (0)
+
+namespace {
+
+constexpr int kB = 256, kQ = 4, kT = kB * kQ; // scan tile: 1024 k-mer start positions
+
+struct DevBuf { // frees everything it allocated when it goes out of scope
+    std::vector<void *> ptrs;
+    ~DevBuf() { for (void *p : ptrs) (void)hipFree(p); }
+    template <class T>
+    hipError_t alloc(T **p, uint64_t count) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, std::max<uint64_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(q);
+        *p = (T *)q;
+        return e;
+    }
+    void release(void *p) {
+        for (auto &q : ptrs) if (q == p) { (void)hipFree(p); q = nullptr; }
+    }
+};
+
+struct ScanParams {
+    const uint64_t *useq;   // plain packed sequence (+2 pad words)
+    const uint64_t *seqbv;  // interleaved records (unitig boundaries)
+    uint64_t total_len, seed;
+    uint32_t k, w, key_shift; // key = (word << key_shift) | (pos << 1) | cls
+};
+
+// G1: one key per k-mer start position; a key is kept when it differs from its left neighbour's (the
+// reference drops consecutive duplicates per strand class, sshash.rs:109-134; the unique pass after the sort
+// removes what is left).  STORE == false only counts.
+template <bool STORE>
+__global__ __launch_bounds__(kB) void scan_minimizers_kernel(ScanParams P, uint64_t n_tiles, uint64_t *__restrict__ out_keys,
+                                                             unsigned long long *counter) {
+    __shared__ uint64_t hf[kT + 32], hr[kT + 32];
+    __shared__ uint64_t keys[kT];
+    const uint32_t t = threadIdx.x, k = P.k, w = P.w, n_win = k - w + 1;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t P0 = tile * kT;
+        for (uint32_t j = t; j < kT + n_win - 1; j += kB) { // w-mer hashes of the tile, both strands
+            uint64_t p = P0 + j;
+            uint64_t m = p + w <= P.total_len ? read_kmer(P.useq, p, w) : 0;
+            hf[j] = hash_mmer(m, P.seed, w);
+            hr[j] = hash_mmer(kmer_rc(m, w), P.seed, w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const uint32_t i = q * kB + t;
+            const uint64_t p = P0 + i;
+            uint64_t key = ~0ull;
+            if (p + k <= P.total_len) {
+                UnitigSpan s = locate_unitig_i(P.seqbv, p);
+                if (p + k <= s.end) {
+                    const uint64_t fw = read_kmer(P.useq, p, k), rc = kmer_rc(fw, k);
+                    if (fw <= rc) { // forward-canonical: leftmost minimum of the forward hashes
+                        uint32_t bo = 0;
+                        uint64_t bh = hf[i];
+                        for (uint32_t o = 1; o < n_win; ++o) { uint64_t h = hf[i + o]; if (h < bh) { bh = h; bo = o; } }
+                        key = (((fw >> (2 * bo)) & kmer_mask(w)) << P.key_shift) | ((p + bo) << 1);
+                    } else { // reverse-canonical: rightmost minimum of the reverse hashes; word of g* = rc of the forward w-mer
+                        uint32_t bj = 0;
+                        uint64_t bh = hr[i];
+                        for (uint32_t j = 1; j < n_win; ++j) { uint64_t h = hr[i + j]; if (h <= bh) { bh = h; bj = j; } }
+                        const uint32_t og = (k - w) - bj; // offset inside g* = rc
+                        key = (((rc >> (2 * og)) & kmer_mask(w)) << P.key_shift) | ((p + bj) << 1) | 1u;
+                    }
+                }
+            }
+            keys[i] = key;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const uint32_t i = q * kB + t;
+            const uint64_t key = keys[i];
+            const bool emit = key != ~0ull && (i == 0 || keys[i - 1] != key);
+            unsigned long long b = __ballot(emit);
+            if (b) {
+                unsigned lane = __lane_id(), leader = (unsigned)(__ffsll((long long)b) - 1);
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(b));
+                base = __shfl(base, (int)leader);
+                if (STORE && emit) out_keys[base + __popcll(b & ((1ull << lane) - 1))] = key;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct KeyToWord {
+    uint32_t shift;
+    __host__ __device__ uint64_t operator()(uint64_t key) const { return key >> shift; }
+};
+
+__global__ __launch_bounds__(kB) void set_member_bits_kernel(const uint64_t *__restrict__ words, uint64_t n, uint64_t *minrec) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
+        uint32_t x = (uint32_t)words[i], bit = x & ((1u << kMinRecKeysLog2) - 1);
+        atomicOr((unsigned long long *)&minrec[(uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords + 1 + (bit >> 6)], 1ull << (bit & 63));
+    }
+}
+__global__ __launch_bounds__(kB) void record_counts_kernel(const uint64_t *__restrict__ minrec, uint64_t n_rec, uint64_t *__restrict__ counts) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < n_rec; j += stride) {
+        const uint64_t *W = minrec + j * kMinRecWords;
+        counts[j] = popc64(W[1]) + popc64(W[2]) + popc64(W[3]) + popc64(W[4]);
+    }
+}
+// ranks + Elias-Fano half of every minimizer record (Mphf::build_direct + fill_bucket_offsets of the host)
+__global__ __launch_bounds__(kB) void finish_records_kernel(uint64_t *minrec, uint64_t n_rec, const uint64_t *__restrict__ rank0, const uint64_t *__restrict__ counts,
+                                                            const uint64_t *__restrict__ psum, uint64_t n_psum, unsigned long long *n_overflow) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < n_rec; j += stride) {
+        uint64_t *W = minrec + j * kMinRecWords;
+        const uint64_t r0 = rank0[j];
+        const uint32_t c = (uint32_t)counts[j];
+        W[0] = r0;
+        W[8] = 1ull << 63;
+        if (c == 0) continue;
+        uint64_t xs[kBefSpan + 1], enc[8];
+        bool ok = c <= kBefSpan && r0 + c < n_psum;
+        if (ok) {
+            for (uint32_t q = 0; q <= c; ++q) xs[q] = psum[r0 + q];
+            ok = bef_encode_block(xs, c, enc);
+        }
+        if (ok) for (int q = 0; q < 8; ++q) W[8 + q] = enc[q];
+        else atomicAdd(n_overflow, 1ull);
+    }
+}
+// global partitioned Elias-Fano over psum (BlockedEF::build): block encode + overflow flag
+__global__ __launch_bounds__(kB) void bef_blocks_kernel(const uint64_t *__restrict__ psum, uint64_t n, uint64_t n_blocks, uint64_t *__restrict__ blocks,
+                                                        uint64_t *__restrict__ ovflag) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < n_blocks; j += stride) {
+        uint64_t first = j << kBefShift, last = first + kBefSpan < n - 1 ? first + kBefSpan : n - 1;
+        uint64_t xs[kBefSpan + 1], enc[8];
+        uint32_t cnt = (uint32_t)(last - first);
+        for (uint32_t q = 0; q <= cnt; ++q) xs[q] = psum[first + q];
+        bool ok = bef_encode_block(xs, cnt, enc);
+        for (int q = 0; q < 8; ++q) blocks[j * 8 + q] = ok ? enc[q] : 0;
+        ovflag[j] = ok ? 0 : 1;
+    }
+}
+__global__ __launch_bounds__(kB) void bef_overflow_kernel(const uint64_t *__restrict__ psum, uint64_t n, uint64_t n_blocks, const uint64_t *__restrict__ ovflag,
+                                                          const uint64_t *__restrict__ ovrank, uint64_t *blocks, uint64_t *__restrict__ ovf) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < n_blocks; j += stride) {
+        if (!ovflag[j]) continue;
+        uint64_t first = j << kBefShift, off = ovrank[j] * (kBefSpan + 1);
+        for (uint32_t q = 0; q <= kBefSpan; ++q) ovf[off + q] = psum[first + q < n - 1 ? first + q : n - 1];
+        blocks[j * 8] = off | (1ull << 63);
+    }
+}
+// packed `pos` entries (PackedVec::assign of make_entry(pos, cls, flank)); words are pre-zeroed
+__global__ __launch_bounds__(kB) void pos_entries_kernel(const uint64_t *__restrict__ keys, uint64_t n, ScanParams P, uint32_t width, uint64_t *packed) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    const uint64_t pmask = (1ull << P.key_shift) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
+        const uint64_t key = keys[i], pc = key & pmask, pos = pc >> 1;
+        const uint64_t ent = make_entry(pos, (uint32_t)(pc & 1), flank_of(P.useq, P.total_len, pos, P.w));
+        const uint64_t b = i * width, wi = b >> 6;
+        const uint32_t sh = (uint32_t)(b & 63);
+        atomicOr((unsigned long long *)&packed[wi], ent << sh);
+        if (sh + width > 64) atomicOr((unsigned long long *)&packed[wi + 1], ent >> (64 - sh));
+    }
+}
+
+// ---- skew index ----
+// tuples around every occurrence of a heavy minimizer (sshash.rs:231-262): one lane per (occurrence, offset)
+template <bool STORE>
+__global__ __launch_bounds__(kB) void skew_tuples_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ run_start, const uint64_t *__restrict__ run_len,
+                                                         uint64_t n_mm, ScanParams P, uint64_t skew_param, uint64_t *__restrict__ out_word,
+                                                         uint64_t *__restrict__ out_pos, unsigned long long *counter) {
+    // grid-stride over minimizers; heavy ones are walked by the whole workgroup
+    const uint64_t pmask = (1ull << P.key_shift) - 1;
+    const uint32_t k = P.k, w = P.w, span = k - w + 1;
+    for (uint64_t i = blockIdx.x; i < n_mm; i += gridDim.x) {
+        const uint64_t len = run_len[i];
+        if (len <= skew_param) continue;
+        const uint64_t s = run_start[i], items = len * span;
+        for (uint64_t x0 = 0; x0 < items; x0 += kB) {
+            const uint64_t x = x0 + threadIdx.x;
+            bool emit = false;
+            uint64_t word = 0, p = 0;
+            if (x < items) {
+                const uint64_t occ = x / span, off = x - occ * span;
+                const uint64_t mp = (keys[s + occ] & pmask) >> 1;
+                const uint64_t start_pos = mp < (uint64_t)(k - w) ? 0 : mp - (k - w);
+                p = start_pos + off;
+                if (p + k <= P.total_len) {
+                    UnitigSpan sp = locate_unitig_i(P.seqbv, p);
+                    if (p + k <= sp.end) {
+                        const uint64_t fw = read_kmer(P.useq, p, k), rc = kmer_rc(fw, k);
+                        word = fw < rc ? fw : rc;
+                        emit = true;
+                    }
+                }
+            }
+            unsigned long long b = __ballot(emit);
+            if (b) {
+                unsigned lane = __lane_id(), leader = (unsigned)(__ffsll((long long)b) - 1);
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(b));
+                base = __shfl(base, (int)leader);
+                if (STORE && emit) {
+                    unsigned long long slot = base + __popcll(b & ((1ull << lane) - 1));
+                    out_word[slot] = word;
+                    out_pos[slot] = p;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kB) void bbhash_mark_kernel(const uint64_t *__restrict__ keys, uint64_t n, MphfLevel L, uint64_t *occ, uint64_t *col) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
+        uint32_t blk, bit;
+        mphf_level_slot(keys[i], L.seed, L.n_blocks, blk, bit);
+        const uint64_t wi = (uint64_t)blk * kMphfDataWords + (bit >> 6), m = 1ull << (bit & 63);
+        const unsigned long long old = atomicOr((unsigned long long *)&occ[wi], m);
+        if (old & m) atomicOr((unsigned long long *)&col[wi], m);
+    }
+}
+// occ &= ~col, write the interleaved block (data words + 9-bit sub-counts), per-block popcount
+__global__ __launch_bounds__(kB) void bbhash_blocks_kernel(uint64_t *occ, const uint64_t *__restrict__ col, uint64_t n_blocks, uint64_t *__restrict__ blocks,
+                                                           uint64_t *__restrict__ block_ones) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n_blocks; i += stride) {
+        uint64_t sub = 0, c = 0;
+        for (uint32_t j = 0; j < kMphfDataWords; ++j) {
+            const uint64_t wv = occ[i * kMphfDataWords + j] & ~col[i * kMphfDataWords + j];
+            occ[i * kMphfDataWords + j] = wv;
+            blocks[i * 8 + 2 + j] = wv;
+            sub |= c << (9 * j);
+            c += popc64(wv);
+        }
+        blocks[i * 8 + 1] = sub;
+        blocks[i * 8 + 0] = 0;
+        block_ones[i] = c;
+    }
+}
+struct NotPlaced { // keys whose bit did not survive go to the next level
+    const uint64_t *occ;
+    MphfLevel L;
+    __host__ __device__ bool operator()(uint64_t key) const {
+        uint32_t blk, bit;
+        mphf_level_slot(key, L.seed, L.n_blocks, blk, bit);
+        return !((occ[(uint64_t)blk * kMphfDataWords + (bit >> 6)] >> (bit & 63)) & 1);
+    }
+};
+__global__ __launch_bounds__(kB) void set_block_ranks_kernel(uint64_t *blocks, const uint64_t *__restrict__ ranks, uint64_t n_blocks) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n_blocks; i += stride) blocks[i * 8] = ranks[i];
+}
+__global__ __launch_bounds__(kB) void skew_pos_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pos, uint64_t n, MphfView m, uint32_t width,
+                                                      uint64_t *packed) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
+        uint64_t h = 0;
+        mphf_lookup(m, words[i], h);
+        const uint64_t b = h * width, wi = b >> 6, v = pos[i];
+        const uint32_t sh = (uint32_t)(b & 63);
+        atomicOr((unsigned long long *)&packed[wi], v << sh);
+        if (sh + width > 64) atomicOr((unsigned long long *)&packed[wi + 1], v >> (64 - sh));
+    }
+}
+__global__ __launch_bounds__(kB) void first_of_run_kernel(const uint64_t *__restrict__ words, uint64_t n, uint8_t *__restrict__ flag) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) flag[i] = i == 0 || words[i] != words[i - 1];
+}
+
+unsigned grid_of(uint64_t n, unsigned cap = 256 * 32) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kB - 1) / kB, cap)); }
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// rocPRIM calls: size query, allocate, run
+#define ROCPRIM_RUN(buf, call_with_tmp)                                   \
+    do {                                                                  \
+        void *tmp = nullptr;                                              \
+        size_t tmp_bytes = 0;                                             \
+        BG_HIP(call_with_tmp);                                            \
+        BG_HIP((buf).alloc((char **)&tmp, tmp_bytes));                    \
+        BG_HIP(call_with_tmp);                                            \
+        BG_HIP(hipDeviceSynchronize());                                   \
+        (buf).release(tmp);                                               \
+    } while (0)
+
+template <class T>
+int download(std::vector<T> &dst, const T *src, uint64_t n) {
+    dst.resize(n);
+    if (n) BG_HIP(hipMemcpy(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost));
+    return MZ_OK;
+}
+
+} // namespace
+
+bool gpu_build_supported(const UnitigSet &us, uint32_t w) {
+    if (w == 0 || w > us.k || 2 * w > 32) return false;
+    if (2 * w + bit_len(us.total_len) + 1 > 64) return false;
+    uint64_t rec_bytes = (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords * 8;
+    return rec_bytes <= (8ull << 30); // the host rule additionally needs >= rec_bytes/16 minimizers; checked after G2
+}
+
+// returns MZ_OK and fills `h` like SSHashHost::build, or MZ_EINVAL with last_error "unsupported" (caller falls back)
+int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device) {
+    const double t_begin = now_s();
+    const bool timing = std::getenv("MZ_BUILD_TIMING") != nullptr;
+    double tp = t_begin;
+    auto phase = [&](const char *name) {
+        if (timing) { (void)hipDeviceSynchronize(); double t = now_s(); std::fprintf(stderr, "[mz gpu build] %-28s %7.3f s\n", name, t - tp); tp = t; }
+    };
+    if (!gpu_build_supported(unitigs, w)) { set_error("GPU build unsupported for this (w, length)"); return MZ_EINVAL; }
+    if (device_count() <= 0) { set_error("no HIP device visible"); return MZ_EHIP; }
+    BG_HIP(hipSetDevice(device));
+    h.us = unitigs;
+    h.w = w; h.seed = seed; h.skew_param = skew_param; h.has_skew = false;
+    const UnitigSet &us = h.us;
+    const uint32_t k = us.k;
+    DevBuf buf;
+    ScanParams P{};
+    uint64_t *d_useq = nullptr, *d_seqbv = nullptr;
+    BG_HIP(buf.alloc(&d_useq, us.useq.size()));
+    BG_HIP(buf.alloc(&d_seqbv, us.seqbv.size()));
+    BG_HIP(hipMemcpy(d_useq, us.useq.data(), us.useq.size() * 8, hipMemcpyHostToDevice));
+    BG_HIP(hipMemcpy(d_seqbv, us.seqbv.data(), us.seqbv.size() * 8, hipMemcpyHostToDevice));
+    P.useq = d_useq; P.seqbv = d_seqbv; P.total_len = us.total_len; P.seed = seed; P.k = k; P.w = w;
+    P.key_shift = bit_len(us.total_len) + 1;
+    phase("upload sequence");
+
+    // ---- G1: count, then store
+    unsigned long long *d_counter = nullptr;
+    BG_HIP(buf.alloc(&d_counter, 4));
+    BG_HIP(hipMemset(d_counter, 0, 32));
+    const uint64_t n_tiles = us.total_len >= k ? (us.total_len - k + 1 + kT - 1) / kT : 0;
+    if (n_tiles == 0) { set_error("SSHash: no k-mers (every unitig shorter than k=%u)", k); return MZ_EEMPTY; }
+    const unsigned sgrid = (unsigned)std::min<uint64_t>(n_tiles, 256 * 64);
+    hipLaunchKernelGGL(scan_minimizers_kernel<false>, dim3(sgrid), dim3(kB), 0, 0, P, n_tiles, (uint64_t *)nullptr, d_counter);
+    uint64_t n_raw = 0;
+    BG_HIP(hipMemcpy(&n_raw, d_counter, 8, hipMemcpyDeviceToHost));
+    if (n_raw == 0) { set_error("SSHash: no k-mers (every unitig shorter than k=%u)", k); return MZ_EEMPTY; }
+    uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
+    BG_HIP(buf.alloc(&d_keys, n_raw));
+    BG_HIP(buf.alloc(&d_keys2, n_raw));
+    BG_HIP(hipMemset(d_counter, 0, 8));
+    hipLaunchKernelGGL(scan_minimizers_kernel<true>, dim3(sgrid), dim3(kB), 0, 0, P, n_tiles, d_keys, d_counter);
+    BG_HIP(hipGetLastError());
+    phase("G1 minimizer scan");
+
+    // ---- G2: sort, unique, run-length
+    const unsigned key_bits = 2 * w + P.key_shift;
+    ROCPRIM_RUN(buf, rocprim::radix_sort_keys(tmp, tmp_bytes, d_keys, d_keys2, n_raw, 0, key_bits));
+    uint64_t *d_nsel = nullptr;
+    BG_HIP(buf.alloc(&d_nsel, 2));
+    ROCPRIM_RUN(buf, rocprim::unique(tmp, tmp_bytes, d_keys2, d_keys, d_nsel, n_raw));
+    uint64_t n_occ = 0;
+    BG_HIP(hipMemcpy(&n_occ, d_nsel, 8, hipMemcpyDeviceToHost));
+    buf.release(d_keys2);
+    auto words_it = rocprim::make_transform_iterator(d_keys, KeyToWord{P.key_shift});
+    uint64_t *d_mm = nullptr, *d_cnt = nullptr;
+    BG_HIP(buf.alloc(&d_mm, n_occ));
+    BG_HIP(buf.alloc(&d_cnt, n_occ + 1));
+    ROCPRIM_RUN(buf, rocprim::run_length_encode(tmp, tmp_bytes, words_it, n_occ, d_mm, d_cnt, d_nsel));
+    uint64_t n_mm = 0;
+    BG_HIP(hipMemcpy(&n_mm, d_nsel, 8, hipMemcpyDeviceToHost));
+    h.n_minimizers = n_mm;
+    {   // same rule as the host builder: records must stay small next to the key set
+        uint64_t rec_bytes = (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords * 8;
+        if (rec_bytes > std::max<uint64_t>(64ull << 20, 16 * n_mm)) { set_error("GPU build unsupported: host rule selects the BBHash minimizer MPHF"); return MZ_EINVAL; }
+    }
+    // bucket starts: psum[i] = occurrences before minimizer i (n_mm + 1 values); run_start == psum in monotone mode
+    uint64_t *d_psum = nullptr;
+    BG_HIP(buf.alloc(&d_psum, n_mm + 1));
+    BG_HIP(hipMemset(d_cnt + n_mm, 0, 8));
+    ROCPRIM_RUN(buf, rocprim::exclusive_scan(tmp, tmp_bytes, d_cnt, d_psum, (uint64_t)0, n_mm + 1, rocprim::plus<uint64_t>()));
+    phase("G2 sort/unique/run-length");
+
+    // ---- G3: minimizer records
+    const uint64_t n_rec = ((1ull << (2 * w)) >> kMinRecKeysLog2) + 1;
+    uint64_t *d_minrec = nullptr, *d_rcnt = nullptr, *d_rrank = nullptr;
+    BG_HIP(buf.alloc(&d_minrec, n_rec * kMinRecWords));
+    BG_HIP(buf.alloc(&d_rcnt, n_rec));
+    BG_HIP(buf.alloc(&d_rrank, n_rec));
+    BG_HIP(hipMemset(d_minrec, 0, n_rec * kMinRecWords * 8));
+    hipLaunchKernelGGL(set_member_bits_kernel, dim3(grid_of(n_mm)), dim3(kB), 0, 0, d_mm, n_mm, d_minrec);
+    hipLaunchKernelGGL(record_counts_kernel, dim3(grid_of(n_rec)), dim3(kB), 0, 0, d_minrec, n_rec, d_rcnt);
+    ROCPRIM_RUN(buf, rocprim::exclusive_scan(tmp, tmp_bytes, d_rcnt, d_rrank, (uint64_t)0, n_rec, rocprim::plus<uint64_t>()));
+    BG_HIP(hipMemset(d_counter, 0, 8));
+    hipLaunchKernelGGL(finish_records_kernel, dim3(grid_of(n_rec)), dim3(kB), 0, 0, d_minrec, n_rec, d_rrank, d_rcnt, d_psum, n_mm + 1, d_counter);
+    BG_HIP(hipMemcpy(&h.n_minrec_overflow, d_counter, 8, hipMemcpyDeviceToHost));
+    h.mm.n_keys = n_mm; h.mm.direct = 1; h.mm.levels.clear();
+    if (int rc = download(h.mm.blocks, d_minrec, n_rec * kMinRecWords)) return rc;
+    buf.release(d_minrec); buf.release(d_rcnt); buf.release(d_rrank);
+    phase("G3 minimizer records");
+
+    // global partitioned Elias-Fano over psum
+    {
+        const uint64_t n = n_mm + 1, nb = ((n - 1) >> kBefShift) + 1;
+        uint64_t *d_blocks = nullptr, *d_flag = nullptr, *d_rank = nullptr;
+        BG_HIP(buf.alloc(&d_blocks, nb * 8));
+        BG_HIP(buf.alloc(&d_flag, nb + 1));
+        BG_HIP(buf.alloc(&d_rank, nb + 1));
+        hipLaunchKernelGGL(bef_blocks_kernel, dim3(grid_of(nb)), dim3(kB), 0, 0, d_psum, n, nb, d_blocks, d_flag);
+        BG_HIP(hipMemset(d_flag + nb, 0, 8));
+        ROCPRIM_RUN(buf, rocprim::exclusive_scan(tmp, tmp_bytes, d_flag, d_rank, (uint64_t)0, nb + 1, rocprim::plus<uint64_t>()));
+        uint64_t n_ov = 0;
+        BG_HIP(hipMemcpy(&n_ov, d_rank + nb, 8, hipMemcpyDeviceToHost));
+        h.buckets.n = n; h.buckets.n_overflow = n_ov;
+        if (n_ov) {
+            uint64_t *d_ovf = nullptr;
+            BG_HIP(buf.alloc(&d_ovf, n_ov * (kBefSpan + 1)));
+            hipLaunchKernelGGL(bef_overflow_kernel, dim3(grid_of(nb)), dim3(kB), 0, 0, d_psum, n, nb, d_flag, d_rank, d_blocks, d_ovf);
+            if (int rc = download(h.buckets.ovf, d_ovf, n_ov * (kBefSpan + 1))) return rc;
+            buf.release(d_ovf);
+        } else {
+            h.buckets.ovf.assign(2, 0);
+        }
+        if (int rc = download(h.buckets.blocks, d_blocks, nb * 8)) return rc;
+        buf.release(d_blocks); buf.release(d_flag); buf.release(d_rank);
+    }
+    // packed pos entries
+    {
+        h.pos.n = n_occ;
+        h.pos.width = bit_len(make_entry(us.total_len, 1, 0xFFFF));
+        const uint64_t n_words = (n_occ * h.pos.width + 63) / 64 + 2;
+        uint64_t *d_packed = nullptr;
+        BG_HIP(buf.alloc(&d_packed, n_words));
+        BG_HIP(hipMemset(d_packed, 0, n_words * 8));
+        hipLaunchKernelGGL(pos_entries_kernel, dim3(grid_of(n_occ)), dim3(kB), 0, 0, d_keys, n_occ, P, h.pos.width, d_packed);
+        if (int rc = download(h.pos.w, d_packed, n_words)) return rc;
+        buf.release(d_packed);
+    }
+    phase("G3 offsets + pos entries");
+
+    // ---- G4: skew index
+    if (skew_param != ~0ull) {
+        BG_HIP(hipMemset(d_counter, 0, 8));
+        const unsigned kgrid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(n_mm, 1), 256 * 64);
+        hipLaunchKernelGGL(skew_tuples_kernel<false>, dim3(kgrid), dim3(kB), 0, 0, d_keys, d_psum, d_cnt, n_mm, P, skew_param, (uint64_t *)nullptr,
+                           (uint64_t *)nullptr, d_counter);
+        uint64_t n_tup = 0;
+        BG_HIP(hipMemcpy(&n_tup, d_counter, 8, hipMemcpyDeviceToHost));
+        uint64_t *d_tw = nullptr, *d_tp = nullptr, *d_tw2 = nullptr, *d_tp2 = nullptr;
+        BG_HIP(buf.alloc(&d_tw, n_tup)); BG_HIP(buf.alloc(&d_tp, n_tup));
+        BG_HIP(buf.alloc(&d_tw2, n_tup)); BG_HIP(buf.alloc(&d_tp2, n_tup));
+        uint64_t sn = 0;
+        if (n_tup) {
+            BG_HIP(hipMemset(d_counter, 0, 8));
+            hipLaunchKernelGGL(skew_tuples_kernel<true>, dim3(kgrid), dim3(kB), 0, 0, d_keys, d_psum, d_cnt, n_mm, P, skew_param, d_tw, d_tp, d_counter);
+            // sort by (word, pos): stable sort by pos, then by word; keep the first tuple of every word
+            ROCPRIM_RUN(buf, rocprim::radix_sort_pairs(tmp, tmp_bytes, d_tp, d_tp2, d_tw, d_tw2, n_tup, 0, bit_len(us.total_len)));
+            ROCPRIM_RUN(buf, rocprim::radix_sort_pairs(tmp, tmp_bytes, d_tw2, d_tw, d_tp2, d_tp, n_tup, 0, 2 * k));
+            uint8_t *d_first = nullptr;
+            BG_HIP(buf.alloc(&d_first, n_tup));
+            hipLaunchKernelGGL(first_of_run_kernel, dim3(grid_of(n_tup)), dim3(kB), 0, 0, d_tw, n_tup, d_first);
+            ROCPRIM_RUN(buf, rocprim::select(tmp, tmp_bytes, d_tw, d_first, d_tw2, d_nsel, n_tup));
+            ROCPRIM_RUN(buf, rocprim::select(tmp, tmp_bytes, d_tp, d_first, d_tp2, d_nsel, n_tup));
+            BG_HIP(hipMemcpy(&sn, d_nsel, 8, hipMemcpyDeviceToHost));
+            buf.release(d_first);
+        }
+        phase("G4 skew tuples + sort");
+        // BBHash levels over d_tw2[0..sn) (Mphf::build of the host, same seeds / sizes / gamma)
+        Mphf &m = h.skew;
+        m.n_keys = sn; m.direct = 0; m.levels.clear(); m.blocks.clear();
+        uint64_t *d_kcur = d_tw, *d_knext = nullptr; // d_tw is free again: reuse as the live key list
+        if (sn) BG_HIP(hipMemcpy(d_kcur, d_tw2, sn * 8, hipMemcpyDeviceToDevice));
+        BG_HIP(buf.alloc(&d_knext, sn));
+        uint64_t rem = sn, total_blocks = 0, lvl_seed = 0x9E3779B97F4A7C15ull;
+        std::vector<uint64_t *> lvl_blocks;
+        std::vector<uint64_t> lvl_nb;
+        uint64_t *d_ones_all = nullptr; // per-block popcounts of all levels, concatenated later
+        std::vector<uint64_t *> lvl_ones;
+        while (rem > 0) {
+            if (m.levels.size() >= kMphfMaxLevels) { set_error("MPHF: more than %u levels (duplicate keys?)", kMphfMaxLevels); return MZ_EINVAL; }
+            const uint64_t nb = (uint64_t)((1.7 * (double)rem) / kMphfBitsPerBlock) + 1;
+            lvl_seed = lvl_seed * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull;
+            MphfLevel L{total_blocks, lvl_seed, (uint32_t)nb, 0};
+            uint64_t *d_occ = nullptr, *d_col = nullptr, *d_blk = nullptr, *d_ones = nullptr;
+            BG_HIP(buf.alloc(&d_occ, nb * kMphfDataWords)); BG_HIP(buf.alloc(&d_col, nb * kMphfDataWords));
+            BG_HIP(buf.alloc(&d_blk, nb * 8)); BG_HIP(buf.alloc(&d_ones, nb));
+            BG_HIP(hipMemset(d_occ, 0, nb * kMphfDataWords * 8)); BG_HIP(hipMemset(d_col, 0, nb * kMphfDataWords * 8));
+            hipLaunchKernelGGL(bbhash_mark_kernel, dim3(grid_of(rem)), dim3(kB), 0, 0, d_kcur, rem, L, d_occ, d_col);
+            hipLaunchKernelGGL(bbhash_blocks_kernel, dim3(grid_of(nb)), dim3(kB), 0, 0, d_occ, d_col, nb, d_blk, d_ones);
+            ROCPRIM_RUN(buf, rocprim::select(tmp, tmp_bytes, d_kcur, d_knext, d_nsel, rem, NotPlaced{d_occ, L}));
+            uint64_t nr = 0;
+            BG_HIP(hipMemcpy(&nr, d_nsel, 8, hipMemcpyDeviceToHost));
+            buf.release(d_occ); buf.release(d_col);
+            lvl_blocks.push_back(d_blk); lvl_nb.push_back(nb); lvl_ones.push_back(d_ones);
+            m.levels.push_back(L);
+            total_blocks += nb;
+            std::swap(d_kcur, d_knext);
+            rem = nr;
+        }
+        (void)d_ones_all;
+        // absolute ranks over the concatenated levels
+        if (total_blocks) {
+            uint64_t *d_all = nullptr, *d_ones = nullptr, *d_ranks = nullptr;
+            BG_HIP(buf.alloc(&d_all, total_blocks * 8)); BG_HIP(buf.alloc(&d_ones, total_blocks)); BG_HIP(buf.alloc(&d_ranks, total_blocks));
+            uint64_t off = 0;
+            for (size_t l = 0; l < lvl_nb.size(); ++l) {
+                BG_HIP(hipMemcpy(d_all + off * 8, lvl_blocks[l], lvl_nb[l] * 64, hipMemcpyDeviceToDevice));
+                BG_HIP(hipMemcpy(d_ones + off, lvl_ones[l], lvl_nb[l] * 8, hipMemcpyDeviceToDevice));
+                buf.release(lvl_blocks[l]); buf.release(lvl_ones[l]);
+                off += lvl_nb[l];
+            }
+            ROCPRIM_RUN(buf, rocprim::exclusive_scan(tmp, tmp_bytes, d_ones, d_ranks, (uint64_t)0, total_blocks, rocprim::plus<uint64_t>()));
+            hipLaunchKernelGGL(set_block_ranks_kernel, dim3(grid_of(total_blocks)), dim3(kB), 0, 0, d_all, d_ranks, total_blocks);
+            if (int rc = download(m.blocks, d_all, total_blocks * 8)) return rc;
+            // skew_pos[h(word)] = pos, packed at bit_len(total_len)
+            MphfLevel *d_levels = nullptr;
+            BG_HIP(buf.alloc(&d_levels, m.levels.size()));
+            BG_HIP(hipMemcpy(d_levels, m.levels.data(), m.levels.size() * sizeof(MphfLevel), hipMemcpyHostToDevice));
+            MphfView mv{d_all, d_levels, (uint32_t)m.levels.size(), 0, sn};
+            h.skew_pos.n = sn;
+            h.skew_pos.width = bit_len(us.total_len);
+            const uint64_t n_words = (sn * h.skew_pos.width + 63) / 64 + 2;
+            uint64_t *d_sp = nullptr;
+            BG_HIP(buf.alloc(&d_sp, n_words));
+            BG_HIP(hipMemset(d_sp, 0, n_words * 8));
+            hipLaunchKernelGGL(skew_pos_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_tw2, d_tp2, sn, mv, h.skew_pos.width, d_sp);
+            if (int rc = download(h.skew_pos.w, d_sp, n_words)) return rc;
+        } else {
+            m.blocks.assign(8, 0);
+            h.skew_pos.n = 0;
+            h.skew_pos.width = bit_len(us.total_len);
+            h.skew_pos.w.assign(2, 0);
+        }
+        h.has_skew = true;
+        phase("G4 skew mphf + pos");
+    }
+    BG_HIP(hipDeviceSynchronize());
+    BG_HIP(hipGetLastError());
+    h.build_seconds = now_s() - t_begin;
+    return MZ_OK;
+}
+
+} // namespace mz

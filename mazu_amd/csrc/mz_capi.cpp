@@ -119,6 +119,24 @@ int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew
     *out = ix;
     return MZ_OK;
 }
+int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int device, mz_sshash **out) {
+    if (!us || !out) { set_error("null argument"); return MZ_EINVAL; }
+    *out = nullptr;
+    if (w == 0 || w > us->us.k) { set_error("SSHash: minimizer size w=%u must be in 1..=k (k=%u)", w, us->us.k); return MZ_EINVAL; }
+    mz_sshash *ix = new (std::nothrow) mz_sshash();
+    if (!ix) return MZ_ENOMEM;
+    int rc = MZ_EINVAL;
+    try {
+        if (gpu_build_supported(us->us, w)) rc = build_on_device(ix->host, us->us, w, skew_param, seed, device);
+        if (rc == MZ_EINVAL) rc = ix->host.build(us->us, w, skew_param, seed, 0); // configuration left to the host builder
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory while building the index");
+        rc = MZ_ENOMEM;
+    }
+    if (rc != MZ_OK) { delete ix; return rc; }
+    *out = ix;
+    return MZ_OK;
+}
 void mz_sshash_free(mz_sshash *ix) {
     if (!ix) return;
     for (DeviceIndex *r : ix->replicas) device_free(r);

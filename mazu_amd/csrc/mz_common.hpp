@@ -276,6 +276,29 @@ MZ_HD bool bef_block_pair(const uint64_t *b, uint32_t t, const uint64_t *ovf, ui
     else { v0 = base + r_a; v1 = base + r_b; }
     return true;
 }
+// Encode xs[0..cnt] (cnt <= 64 elements after the base xs[0]) into one 8-word partitioned-EF block
+// (layout: BefView in mz_common.hpp).  Missing elements are padded with copies of the last value so
+// the unary part always holds 64 ones.  Returns false (W untouched) when it does not fit.
+MZ_HD bool bef_encode_block(const uint64_t *xs, uint32_t cnt, uint64_t *W) {
+    const uint64_t base = xs[0], span = xs[cnt] - base;
+    uint32_t l = 0;
+    bool fits = false;
+    for (l = span >= kBefSpan ? (uint32_t)msb(span / kBefSpan) : 0; l <= kBefMaxL; ++l) {
+        uint64_t high_bits = (span >> l) + kBefSpan + 1;
+        if (high_bits + 64ull * l <= 448) { fits = true; break; }
+    }
+    if (!fits || base >= (1ull << 40)) return false;
+    for (int q = 0; q < 8; ++q) W[q] = 0;
+    W[0] = base | ((uint64_t)l << 40);
+    for (uint32_t t = 1; t <= kBefSpan; ++t) {
+        uint64_t r = xs[t <= cnt ? t : cnt] - base;
+        uint64_t hb = (r >> l) + (t - 1);
+        W[1 + (hb >> 6)] |= 1ull << (hb & 63);
+        for (uint32_t pl = 0; pl < l; ++pl) W[7 - pl] |= ((r >> pl) & 1) << (t - 1);
+    }
+    return true;
+}
+
 MZ_HD void bef_get_pair(const BefView &e, uint64_t i, uint64_t &v0, uint64_t &v1) {
     bef_block_pair(e.blocks + (i >> kBefShift) * 8, (uint32_t)(i & (kBefSpan - 1)), e.ovf, v0, v1);
 }

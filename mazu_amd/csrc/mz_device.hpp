@@ -36,4 +36,8 @@ int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, hipStream_t s
 int launch_extract_kmers(const DeviceIndex &d, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
                          uint64_t *d_fw, hipStream_t stream);
 
+// index construction on the device (mz_build_gpu.hip); false / MZ_EINVAL when the configuration needs the host builder
+bool gpu_build_supported(const UnitigSet &us, uint32_t w);
+int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device);
+
 } // namespace mz

@@ -156,6 +156,13 @@ class SSHash:  # sshash.rs:39-51
         return cls(h)
 
     @classmethod
+    def from_unitig_set_on_device(cls, unitigs, w, skew_param, seed=0, device=0):
+        """same index, built on the GPU where the configuration allows (bit-identical arrays)"""
+        h = C.c_void_p()
+        check(lib.mz_sshash_from_unitig_set_device(unitigs._h, w, int(skew_param), int(seed), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def from_unitig_set_no_skew_index(cls, unitigs, w, seed=0, n_threads=0):  # sshash.rs:397-403
         return cls.from_unitig_set(unitigs, w, MZ_NO_SKEW_INDEX, seed, n_threads)
 

@@ -356,3 +356,22 @@ def test_reads_edge_shapes(yeast):
     want, ko, oc = orc.k2u_reads(bases, ro, streaming=True)
     assert got.tobytes() == want.tobytes() and list(counts) == oc.tolist()
     assert counts[2] == 40 - k + 1
+
+
+@pytest.mark.parametrize("prefix,w,skew", [(CF_TINY, 3, M.MZ_NO_SKEW_INDEX), (CF_TINY, 5, 0), (CF_TINY, 1, 2), (CF_TINY, 7, M.MZ_NO_SKEW_INDEX),
+                                           (CF_YEAST, 12, 16), (CF_YEAST, 13, 32), (CF_YEAST, 9, 4), (CF_YEAST, 4, M.MZ_NO_SKEW_INDEX),
+                                           (CF_YEAST, 15, 16), (CF_YEAST, 20, 8)])
+def test_gpu_built_index_is_bit_identical_to_host_built(prefix, w, skew, tmp_path):
+    """mz_sshash_from_unitig_set_device (minimizer scan, sort, records, EF, entries, skew MPHF on the GPU) must
+    produce the very arrays of the host builder: compared through the flat index file, then queried."""
+    us = M.UnitigSet.from_cf_prefix(prefix)
+    host = M.SSHash.from_unitig_set(us, w, skew)
+    dev = M.SSHash.from_unitig_set_on_device(us, w, skew)   # (15,16) and (20,8) exercise the transparent host fallback
+    host.save(tmp_path / "h.mz")
+    dev.save(tmp_path / "d.mz")
+    a, b = open(tmp_path / "h.mz", "rb").read(), open(tmp_path / "d.mz", "rb").read()
+    assert len(a) == len(b)
+    if a != b:
+        diff = next(i for i in range(len(a)) if a[i] != b[i])
+        raise AssertionError(f"index files differ first at byte {diff} of {len(a)}")
+    dev.validate_self()
