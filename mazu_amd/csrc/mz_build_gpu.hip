@@ -398,6 +398,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
     uint64_t n_occ = 0;
     BG_HIP(hipMemcpy(&n_occ, d_nsel, 8, hipMemcpyDeviceToHost));
     buf.release(d_keys2);
+    if (n_occ >= (1ull << 32)) { set_error("GPU build unsupported: more than 2^32 minimizer occurrences"); return MZ_EINVAL; } // rocPRIM run_length_encode size
     auto words_it = rocprim::make_transform_iterator(d_keys, KeyToWord{P.key_shift});
     uint64_t *d_mm = nullptr, *d_cnt = nullptr;
     BG_HIP(buf.alloc(&d_mm, n_occ));
