@@ -232,3 +232,111 @@ def dense_index_from_pf1(d, k2u_factory):
     u2pos = DenseUnitigTable(f.ctable, f.contig_offsets, f.ref_names)
     refs = RefSeqCollection(f.refseq_words, f.ref_prefix_sum)
     return ModIndex.from_parts({"index_type": "PF1Dense", "info": f.info}, k2u, u2pos, refs), f
+
+
+class SPT:
+    """Spectrum-preserving tiling with pufferfish-packed occurrence lists (reference src/spt.rs:14-152):
+    cuttlefish reduced GFA (`<prefix>.cf_seg` unitigs, `<prefix>.cf_seq` tilings `name\tN3 12+ 7- ...`) ->
+    inverted lists of unitig occurrences.  Host-side ingestion (numpy); the lookups run on the GPU."""
+
+    def __init__(self, k, seqs, ref_names, ctable, offsets, ref_lens):
+        self.k_, self.seqs, self.ref_names = k, seqs, ref_names
+        self.ctable, self.offsets, self.ref_lens = ctable, offsets, ref_lens
+
+    def k(self): return self.k_
+    def n_unitigs(self): return len(self.seqs)
+    def num_refs(self): return len(self.ref_lens)
+    def n_total_occs(self): return len(self.ctable)
+    def ref_name(self, ri): return self.ref_names[ri]
+    def ref_len(self, ri): return int(self.ref_lens[ri])
+
+    def get_occ(self, uid, i):  # spt.rs:56-60 -> (ref_id, pos, forward?)
+        ref_id, pos, fwd = DenseUnitigTable.decode_pf1(self.ctable[int(self.offsets[uid]) + i: int(self.offsets[uid]) + i + 1])
+        return int(ref_id[0]), int(pos[0]), bool(fwd[0])
+
+    @classmethod
+    def from_cf_prefix(cls, prefix):  # spt.rs:62-146
+        import json
+        with open(prefix + ".json") as f:
+            k = json.load(f)["parameters info"]["k"]
+        cfid2uid, seqs = {}, []
+        with open(prefix + ".cf_seg") as f:
+            for line in f:
+                line = line.rstrip("\n")
+                if line:
+                    cid, seq = line.split("\t", 1)
+                    cfid2uid[int(cid)] = len(seqs)   # unitig_set.rs:133-141: sequential ids in line order
+                    seqs.append(seq)
+        ulen = np.array([len(s) for s in seqs], dtype=np.int64)
+        ref_names, occ_uid, occ_word, ref_lens = [], [], [], []
+        with open(prefix + ".cf_seq") as f:
+            for ref_id, line in enumerate(f):
+                name, toks = line.rstrip("\n").split("\t", 1)
+                ref_names.append(name)
+                pos, prev_unitig = 0, False
+                for tok in toks.split(" "):
+                    if not tok:
+                        continue
+                    if tok[0] == "N":            # CfSeqToken::PolyN, spt.rs:104-110
+                        pos += int(tok[1:])
+                        if prev_unitig:
+                            pos += k - 1
+                        prev_unitig = False
+                    else:                        # CfSeqToken::Unitig, spt.rs:111-122
+                        uid = cfid2uid[int(tok[:-1])]
+                        fwd = tok[-1] == "+"
+                        word = ((pos | (0x80000000 if fwd else 0)) << 32) | ref_id   # UnitigOcc::encode_pf1, index.rs:315-331
+                        occ_uid.append(uid)
+                        occ_word.append(word)
+                        pos += int(ulen[uid]) - k + 1
+                        prev_unitig = True
+                ref_lens.append(pos + k - 1 if prev_unitig else pos)
+        occ_uid = np.array(occ_uid, dtype=np.int64)
+        occ_word = np.array(occ_word, dtype=np.uint64)
+        order = np.argsort(occ_uid, kind="stable")       # inverted lists keep tiling order inside a unitig (ctable_ptrs, spt.rs:118-120)
+        offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(np.bincount(occ_uid, minlength=len(seqs)), out=offsets[1:].view(np.int64))
+        return cls(k, seqs, ref_names, occ_word[order], offsets, np.array(ref_lens, dtype=np.uint64))
+
+    def get_ref_seq_collection(self):  # spt.rs:148-153: lengths only, no sequence
+        ps = np.zeros(len(self.ref_lens) + 1, dtype=np.uint64)
+        np.cumsum(self.ref_lens, out=ps[1:])
+        return RefSeqCollection(None, ps)
+
+
+def index_from_cf_prefix(prefix, k2u_factory):
+    """PufferfishDenseIndexDefault::from_cf_prefix (src/index/defaults.rs:16-54) with the K2U slot filled by
+    `k2u_factory(seqs, k)` -- e.g. a GPU SSHash, which makes it the PiscemIndexDefault composition over the
+    dense occurrence table."""
+    spt = SPT.from_cf_prefix(prefix)
+    k2u = k2u_factory(spt.seqs, spt.k())
+    return ModIndex.from_parts({"index_type": "PufferfishDense"}, k2u, DenseUnitigTable(spt.ctable, spt.offsets, spt.ref_names),
+                               spt.get_ref_seq_collection()), spt
+
+
+def validate_fasta_on_device(index, path):
+    """Validate::validate_fasta (src/index/validate.rs:83-100) with the reads kernel, the projection and the
+    assertion on the device; returns the number of k-mers checked."""
+    import torch
+    from .fasta import read_fasta
+    dev = torch.device("cuda", 0)
+    report = torch.tensor([0, 0, -1], dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    k = index.k()
+    n_valid = 0
+    for ri, (_, seq) in enumerate(read_fasta(path)):
+        if len(seq) < k:
+            continue
+        bases = torch.frombuffer(bytearray(seq.encode()), dtype=torch.uint8).to(dev)
+        ro = torch.tensor([0, len(seq)], dtype=torch.int64, device=dev)
+        ko = torch.tensor([0, len(seq) - k + 1], dtype=torch.int64, device=dev)
+        recs = torch.empty(2 * (len(seq) - k + 1), dtype=torch.int64, device=dev)
+        cnt = torch.zeros(3, dtype=torch.int64, device=dev)
+        index.k2u.k2u_reads_device(bases, ro, ko, recs, cnt, streaming=True, stream=stream)
+        check(lib.mz_u2pos_check_refs_device(index.u2pos.handle(), k, recs.data_ptr(), len(seq) - k + 1, ri, report.data_ptr(), stream))
+        torch.cuda.synchronize(dev)
+        n_valid += int(cnt[0].item() + cnt[1].item())
+    n, n_fail, first = report.cpu().tolist()
+    if n_fail:
+        raise AssertionError(f"No MRPs found for {n_fail} true +ve k-mers (first at position {first})")
+    return n_valid

@@ -138,3 +138,26 @@ def test_projection_on_device_matches_host_projection(name, w, skew):  # index.r
         assert [(int(g["ref_id"]), int(g["pos"]), int(g["o"])) for g in got] == [(m.ref_id, m.pos, m.o) for m in want]
         assert (got["query"] == i).all()
     assert idx.u2pos.num_total_occs() == len(f.ctable)
+
+
+def test_spt_tiny_known_answers():  # src/spt.rs:156-211
+    spt = I.SPT.from_cf_prefix(os.path.join(H.GOLDEN, "cf", "tiny", "tiny"))
+    assert spt.num_refs() == 2 and spt.n_total_occs() == 4
+    assert spt.ref_name(0) == "Reference:1_Sequence:I" and spt.ref_len(0) == 3 + 10 + 1 + 10
+    assert spt.get_occ(0, 0) == (0, 3, True)
+    assert spt.get_occ(0, 1) == (1, 10 + 1, False)
+    assert spt.get_occ(1, 0) == (0, 3 + 10 + 1, False)
+    assert spt.get_occ(1, 1) == (1, 0, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,skew", [("tiny", 3, M.MZ_NO_SKEW_INDEX), ("yeast_chr7", 15, 16)])
+def test_index_from_cuttlefish_prefix_validate_fasta(name, w, skew):  # defaults.rs:60-70, piscem_index.rs:63-99
+    prefix = os.path.join(H.GOLDEN, "cf", name, name)
+    idx, spt = I.index_from_cf_prefix(prefix, lambda seqs, k: M.SSHash.from_unitig_set_on_device(M.UnitigSet.from_seqs(seqs, k), w, skew))
+    recs = H.read_fasta(prefix + ".fa")
+    assert [spt.ref_len(i) for i in range(spt.num_refs())] == [len(s) for _, s in recs]
+    n_dev = I.validate_fasta_on_device(idx, prefix + ".fa")       # reads kernel + projection + assertion on the GPU
+    st = idx.as_streaming()                                       # .as_streaming().validate_fasta with the host projection
+    n_host = sum(st.validate_ckmers(ri, seq) for ri, (_, seq) in enumerate(recs))
+    assert n_dev == n_host and n_dev > 0
