@@ -56,7 +56,8 @@ def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads, target_s=8.0):
     t0 = time.time()
     out, n_hit = orc.k2u_batch(q_host[:n], n_threads=n_threads)
     dt = time.time() - t0
-    return out, n_hit, n, n / dt / 1e6, t_build, dt
+    touch_bytes = 8.0 * orc.word_touches(q_host[:min(n, 500_000)])[0]  # measured 8-byte words per query, reference layout
+    return out, n_hit, n, n / dt / 1e6, t_build, dt, touch_bytes
 
 
 def bench_reads(args, ix, us, dev, rank, world, D):
@@ -258,6 +259,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "frac_own_layout": round(batch * B_ALG_OWN / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic_gbs": round(traffic / avg_kernel_s / 1e9, 1) if traffic else None,
                          "kernel": "k2u_batch_kernel(v1)" if os.environ.get("MZ_K2U_KERNEL", "") == "v1" else "k2u_tile_kernel", "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_kmer": B_ALG},
             "build": {"gen_s": round(t_gen, 2), "where": "host" if args.host_build else "gpu", "build_s": round(t_build, 2), "upload_s": round(t_upload, 2),
@@ -268,14 +270,15 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             cores = M.lib.mz_host_threads()  # hardware threads capped by the cgroup CPU quota of this box
             q_host = q[: (args.cpu_sample or batch)].cpu().numpy().view(np.uint64)
-            want, orc_hits, n_sample, cpu_rate, t_ob, t_q = cpu_baseline((words_h, us["total_len"], starts_h), k, args.w, args.skew,
+            want, orc_hits, n_sample, cpu_rate, t_ob, t_q, touch_bytes = cpu_baseline((words_h, us["total_len"], starts_h), k, args.w, args.skew,
                                                                        args.seed, q_host, cores)
             got = out[: 2 * n_sample].cpu().numpy().view(M.K2UPOS_DTYPE)
             same = got.tobytes() == want.tobytes()
             res["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "M k-mers/s", "cores": cores, "kind": "port",
                                    "sample": f"first {n_sample} queries of the rank-0 batch on the same {args.workload} index, "
                                              f"OpenMP static shards over {cores} threads (oracle build {t_ob:.1f}s, query {t_q:.1f}s)",
-                                   "results_identical_to_gpu": same}
+                                   "results_identical_to_gpu": same,
+                                   "word_touch_bytes_per_kmer": round(touch_bytes, 1)}
             res["gpu_over_cpu"] = round(value / cpu_rate, 1)
             assert same, "GPU results differ from the CPU oracle on the sampled queries"
         print(json.dumps(res), flush=True)

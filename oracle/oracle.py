@@ -58,6 +58,8 @@ def lib():
         L.orc_kmer_rc.argtypes = [u64, u32]
         L.orc_util_msb.restype = u64
         L.orc_util_msb.argtypes = [u64]
+        L.orc_word_touches.restype = C.c_double
+        L.orc_word_touches.argtypes = [p, p, u64, p]
         L.orc_ef_roundtrip.restype = C.c_int
         L.orc_ef_roundtrip.argtypes = [p, u64, u64, p]
         _LIB = L
@@ -125,6 +127,13 @@ class OracleSSHash:
         lib().orc_k2u_reads(self.h, _ptr(bases), _ptr(ro), len(ro) - 1, _ptr(ko), 1 if streaming else 0,
                             _ptr(out), _ptr(counts))
         return out, ko, counts
+
+    def word_touches(self, fw_words):
+        """mean 8-byte words read per query in the reference layout (incl. 1 word in, 2 words out), and the hits"""
+        fw = np.ascontiguousarray(fw_words, dtype=np.uint64)
+        nh = C.c_uint64(0)
+        mean = lib().orc_word_touches(self.h, _ptr(fw), len(fw), C.byref(nh))
+        return mean, nh.value
 
     def validate_self(self, use_dict=False):
         return lib().orc_validate_self(self.h, 1 if use_dict else 0)

@@ -48,6 +48,15 @@ typedef struct {
 #define ORC_SKIPPED 3u
 
 /* ------------------------------------------------------------------ */
+/* Word-touch counter: when enabled, every 8-byte word a QUERY reads from the index arrays of
+ * this restatement (reference layout: BBHash levels + rank samples, Elias-Fano high/low/select samples, packed pos,
+ * 2-bit sequence, boundary bit vector + rank samples) is tallied; orc_word_touches() reports the total.  It counts
+ * words per access site (a word read twice by two sites counts twice; the sites of one query rarely overlap). */
+static _Thread_local uint64_t g_touch = 0;
+static int g_touch_on = 0;
+#define TOUCH(n) do { if (g_touch_on) g_touch += (n); } while (0)
+
+/* ------------------------------------------------------------------ */
 /* util.rs:48-55  msb(n): index of most significant bit, msb(0)=0      */
 static uint64_t orc_msb(uint64_t n) { return n == 0 ? 0 : 63u - (uint64_t)__builtin_clzll(n); }
 
@@ -83,6 +92,7 @@ static inline uint64_t iv_get(const intvec *v, uint64_t i) {
     uint64_t b = i * v->width;
     uint64_t wi = b >> 6;
     unsigned sh = (unsigned)(b & 63);
+    TOUCH(sh + v->width > 64 ? 2 : 1);
     uint64_t mask = v->width == 64 ? ~0ull : ((1ull << v->width) - 1);
     uint64_t x = v->w[wi] >> sh;
     if (sh + v->width > 64) x |= v->w[wi + 1] << (64 - sh);
@@ -109,7 +119,7 @@ static void bv_init(bitvec *b, uint64_t n_bits) {
     b->w = (uint64_t *)calloc(b->n_words + 1, 8);
 }
 static inline void bv_set(bitvec *b, uint64_t i) { b->w[i >> 6] |= 1ull << (i & 63); }
-static inline int bv_get(const bitvec *b, uint64_t i) { return (int)((b->w[i >> 6] >> (i & 63)) & 1); }
+static inline int bv_get(const bitvec *b, uint64_t i) { TOUCH(1); return (int)((b->w[i >> 6] >> (i & 63)) & 1); }
 static void bv_enable_rank_select(bitvec *b) {
     b->cum = (uint64_t *)malloc((b->n_words + 1) * 8);
     uint64_t c = 0;
@@ -129,6 +139,7 @@ static void bv_enable_rank_select(bitvec *b) {
     }
 }
 static inline uint64_t bv_rank(const bitvec *b, uint64_t i) {
+    TOUCH(2); /* cumulative count + data word */
     uint64_t wi = i >> 6;
     unsigned sh = (unsigned)(i & 63);
     uint64_t m = sh ? (b->w[wi] & ((1ull << sh) - 1)) : 0;
@@ -136,7 +147,8 @@ static inline uint64_t bv_rank(const bitvec *b, uint64_t i) {
 }
 static inline uint64_t bv_select(const bitvec *b, uint64_t i) {
     uint64_t j = b->sel[i >> 6];
-    while (b->cum[j + 1] <= i) ++j;
+    TOUCH(3); /* select sample + cumulative count + data word */
+    while (b->cum[j + 1] <= i) { ++j; TOUCH(1); }
     uint64_t r = i - b->cum[j];
     uint64_t x = b->w[j];
     while (r--) x &= x - 1;
@@ -198,6 +210,7 @@ static inline int base_code(uint8_t c) {
 static inline uint64_t seq_get_kmer(const uint64_t *w, uint64_t pos, unsigned k) {
     uint64_t b = pos * 2, wi = b >> 6;
     unsigned sh = (unsigned)(b & 63);
+    TOUCH(sh + 2 * k > 64 ? 2 : 1);
     uint64_t x = w[wi] >> sh;
     if (sh) x |= w[wi + 1] << (64 - sh);
     return k == 32 ? x : (x & ((1ull << (2 * k)) - 1));
@@ -793,6 +806,18 @@ uint64_t orc_validate_self(const orc_index *ix, int use_dict) {
         }
     }
     return fails;
+}
+
+/* mean 8-byte words touched per query by orc_k2u over a batch (single thread; +1 word in, +2 words out per query) */
+double orc_word_touches(const orc_index *ix, const uint64_t *fw_words, uint64_t n, uint64_t *n_hit) {
+    orc_k2upos r;
+    uint64_t hits = 0;
+    g_touch = 0;
+    g_touch_on = 1;
+    for (uint64_t i = 0; i < n; ++i) hits += (uint64_t)orc_k2u(ix, fw_words[i], &r);
+    g_touch_on = 0;
+    if (n_hit) *n_hit = hits;
+    return n ? (double)(g_touch + 3 * n) / (double)n : 0.0;
 }
 
 /* ---- accessors for the tests ------------------------------------- */
