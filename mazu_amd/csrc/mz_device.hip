@@ -101,16 +101,33 @@ constexpr bool kSpeculate = MZ_SPECULATE != 0;
 // S.n[i]: bucket size (< kNSkew), or one of the markers below (kNIdle: no query in this slot)
 constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu;
 
-struct TileLds {
-    uint64_t fw[kTileQ];               // forward word of the query
-    uint64_t slot[kTileQ];             // minimizer word -> bucket id h -> bucket start (skew: canonical word -> slot)
-    unsigned long long best[kTileQ];   // (bucket order key << 37) | (twin << 36) | global k-mer position
-    uint32_t n[kTileQ];                // bucket size, kNSkew, kNIdle or kNMiss
-    uint32_t eoff[kTileQ + 1];         // exclusive prefix sum of bucket sizes
-    uint16_t list_a[kTileQ], list_b[kTileQ];
-    uint8_t off[kTileQ];               // minimizer offset inside g*
-    uint32_t cnt_a, cnt_b, cnt_skew, wave_tot[kBlock / 64];
+// Execution scope of a tile: a whole 256-thread workgroup (barriers) or ONE wavefront (no barriers: the four
+// waves of a workgroup then run their own tiles independently and never wait for each other).
+struct BlockScope {
+    static constexpr int NT = kBlock;
+    __device__ static __forceinline__ uint32_t tid() { return threadIdx.x; }
+    __device__ static __forceinline__ void sync() { __syncthreads(); }
 };
+struct WaveScope {
+    static constexpr int NT = 64;
+    __device__ static __forceinline__ uint32_t tid() { return threadIdx.x & 63; }
+    // lanes of one wave execute in lockstep and LDS operations of a wave complete in order: only the compiler has to be
+    // told not to move LDS accesses across this point
+    __device__ static __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+};
+
+template <int NT>
+struct TileLdsT {
+    uint64_t fw[NT * kQpt];               // forward word of the query
+    uint64_t slot[NT * kQpt];             // minimizer word -> bucket id h -> bucket start (skew: canonical word -> slot)
+    unsigned long long best[NT * kQpt];   // (bucket order key << 37) | (twin << 36) | global k-mer position
+    uint32_t n[NT * kQpt];                // bucket size, kNSkew, kNIdle or kNMiss
+    uint32_t eoff[NT * kQpt + 1];         // exclusive prefix sum of bucket sizes
+    uint16_t list_a[NT * kQpt], list_b[NT * kQpt];
+    uint8_t off[NT * kQpt];               // minimizer offset inside g*
+    uint32_t cnt_a, cnt_b, cnt_skew, wave_tot[NT / 64];
+};
+using TileLds = TileLdsT<kBlock>;
 
 // append `idx` of the lanes with pred to an LDS list (one LDS atomic per wave)
 __device__ __forceinline__ void wave_push(uint16_t *list, uint32_t *cnt, bool pred, uint32_t idx) {
@@ -148,25 +165,26 @@ __device__ __forceinline__ bool mphf_eval(const MphfProbe &p, uint64_t &idx) {
 }
 
 // S1 / S4: resolve slot[i] (key) -> MPHF index for the items of list_a[0..cnt_a); items that fall
-// through every level get n[i] = kNMiss.  `dense_first` == all kTileQ items (level 0, no list).
-__device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool dense_first) {
-    const uint32_t t = threadIdx.x;
+// through every level get n[i] = kNMiss.  `dense_first` == all (SC::NT * kQpt) items (level 0, no list).
+template <class SC>
+__device__ __forceinline__ void tile_mphf(TileLdsT<SC::NT> &S, const MphfView &m, bool dense_first) {
+    const uint32_t t = SC::tid();
     uint32_t lv = 0;
     if (dense_first) {
         if (m.n_levels == 0) {
-            for (int q = 0; q < kQpt; ++q) { uint32_t i = q * kBlock + t; if (S.n[i] < kNIdle) S.n[i] = kNMiss; }
+            for (int q = 0; q < kQpt; ++q) { uint32_t i = q * SC::NT + t; if (S.n[i] < kNIdle) S.n[i] = kNMiss; }
             return;
         }
         const MphfLevel L = m.levels[0];
         MphfProbe pr[kQpt];
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            uint32_t i = q * kBlock + t;
+            uint32_t i = q * SC::NT + t;
             pr[q] = mphf_issue(m, L, S.slot[i]);
         }
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            uint32_t i = q * kBlock + t;
+            uint32_t i = q * SC::NT + t;
             uint64_t idx;
             bool hit = mphf_eval(pr[q], idx), act = S.n[i] < kNIdle;
             if (hit && act) S.slot[i] = idx;
@@ -178,12 +196,12 @@ __device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool de
     uint32_t *ccur = &S.cnt_a, *cnxt = &S.cnt_b;
     uint32_t round = 0;
     for (;;) {
-        __syncthreads();
+        SC::sync();
         const uint32_t count = *ccur;
         if (count == 0) break;
         if (lv >= m.n_levels) { // fell through every level: boomphf try_hash -> None
-            for (uint32_t j = t; j < count; j += kBlock) S.n[cur[j]] = kNMiss;
-            __syncthreads();
+            for (uint32_t j = t; j < count; j += SC::NT) S.n[cur[j]] = kNMiss;
+            SC::sync();
             if (t == 0) *ccur = 0;
             break;
         }
@@ -194,7 +212,7 @@ __device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool de
         MphfLevel L[4];
 #pragma unroll
         for (uint32_t a = 0; a < 4; ++a) L[a] = m.levels[lv + (a < nl ? a : 0)];
-        for (uint32_t j = t; j < ((count + 63) & ~63u); j += kBlock) {
+        for (uint32_t j = t; j < ((count + 63) & ~63u); j += SC::NT) {
             bool act = j < count;
             uint32_t i = act ? cur[j] : 0;
             uint64_t key = S.slot[i];
@@ -212,21 +230,23 @@ __device__ __forceinline__ void tile_mphf(TileLds &S, const MphfView &m, bool de
         }
         ++round;
         lv += nl;
-        __syncthreads();
+        SC::sync();
         if (t == 0) *ccur = 0;
         uint16_t *tl = cur; cur = nxt; nxt = tl;
         uint32_t *tc = ccur; ccur = cnxt; cnxt = tc;
     }
-    __syncthreads();
+    SC::sync();
 }
 
 // ---- tile producer / consumer API ------------------------------------------------------
 // A kernel fills the tile with tile_set_query() (S0), calls tile_resolve() (S1-S4) from uniform
 // control flow, then reads each item's answer with tile_result() (S5).
-__device__ __forceinline__ void tile_begin(TileLds &S) {
-    if (threadIdx.x == 0) { S.cnt_a = 0; S.cnt_b = 0; S.cnt_skew = 0; }
+template <class SC>
+__device__ __forceinline__ void tile_begin(TileLdsT<SC::NT> &S) {
+    if (SC::tid() == 0) { S.cnt_a = 0; S.cnt_b = 0; S.cnt_skew = 0; }
 }
-__device__ __forceinline__ void tile_set_query(TileLds &S, uint32_t i, uint64_t fw, Minimizer mn, bool valid) {
+template <class SC>
+__device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, uint64_t fw, Minimizer mn, bool valid) {
     S.fw[i] = fw;
     S.slot[i] = mn.word;
     S.off[i] = (uint8_t)mn.offset;
@@ -234,16 +254,17 @@ __device__ __forceinline__ void tile_set_query(TileLds &S, uint32_t i, uint64_t 
     S.n[i] = valid ? 0u : kNIdle;
 }
 
-__device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
-    const uint32_t t = threadIdx.x, k = ix.k, w = ix.w;
-    __syncthreads();
+template <class SC>
+__device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexView &ix) {
+    const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
+    SC::sync();
     // ---- S1: minimizer -> bucket id.  Direct-address rank bitmap (2w <= 32): one dense gather, no rounds;
     //          otherwise the BBHash level loop
     if (ix.mm.direct) {
         // S1+S2 fused: member test, bucket id and bucket range from ONE 128-byte minimizer record
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            uint32_t i = q * kBlock + t;
+            uint32_t i = q * SC::NT + t;
             bool heavy = false;
             if (S.n[i] < kNIdle) {
                 uint64_t h, ps, pe;
@@ -259,11 +280,11 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
             wave_push(S.list_b, &S.cnt_skew, heavy, i);
         }
     } else {
-        tile_mphf(S, ix.mm, true);
+        tile_mphf<SC>(S, ix.mm, true);
         // ---- S2: bucket range from the partitioned Elias-Fano prefix sums
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            uint32_t i = q * kBlock + t;
+            uint32_t i = q * SC::NT + t;
             bool act = S.n[i] < kNIdle;
             bool heavy = false;
             if (act) {
@@ -277,7 +298,7 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
             wave_push(S.list_b, &S.cnt_skew, heavy, i);
         }
     }
-    __syncthreads();
+    SC::sync();
     // ---- S3: flatten bucket entries (exclusive scan of n over the tile, blocked by thread)
     {
         uint32_t v[kQpt], sum = 0;
@@ -293,28 +314,28 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
             if ((int)(t & 63) >= d) incl += o;
         }
         if ((t & 63) == 63) S.wave_tot[t >> 6] = incl;
-        __syncthreads();
+        SC::sync();
         uint32_t wbase = 0;
         for (uint32_t wv = 0; wv < (t >> 6); ++wv) wbase += S.wave_tot[wv];
         uint32_t excl = wbase + incl - sum;
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) S.eoff[t * kQpt + q] = excl + v[q];
-        if (t == kBlock - 1) S.eoff[kTileQ] = excl + sum;
+        if (t == SC::NT - 1) S.eoff[(SC::NT * kQpt)] = excl + sum;
     }
-    __syncthreads();
+    SC::sync();
     {
-        const uint32_t E = S.eoff[kTileQ];
+        const uint32_t E = S.eoff[(SC::NT * kQpt)];
         const uint64_t last_km_start = ix.total_len - k;
         constexpr int kEpt = 4; // entries in flight per lane: the `pos` gathers are issued together, then the sequence gathers
-        for (uint32_t e0 = t; e0 < E; e0 += kBlock * kEpt) {
+        for (uint32_t e0 = t; e0 < E; e0 += SC::NT * kEpt) {
             uint32_t own[kEpt], jdx[kEpt];
             uint64_t ent[kEpt];
 #pragma unroll
             for (int a = 0; a < kEpt; ++a) {
-                const uint32_t e = e0 + a * kBlock;
+                const uint32_t e = e0 + a * SC::NT;
                 own[a] = 0; jdx[a] = 0; ent[a] = 0;
                 if (e < E) {
-                    uint32_t lo = 0, hi = kTileQ; // owner item: largest i with eoff[i] <= e
+                    uint32_t lo = 0, hi = (SC::NT * kQpt); // owner item: largest i with eoff[i] <= e
                     while (hi - lo > 1) {
                         uint32_t mid = (lo + hi) >> 1;
                         if (S.eoff[mid] <= e) lo = mid; else hi = mid;
@@ -336,7 +357,7 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
                 const uint64_t off = cls ? k - off_a - w : off_a;                    // class 1: candidate B (:527), class 0: A (:498)
                 const uint64_t X = cls ? (fw <= rc ? rc : fw) : (fw <= rc ? fw : rc); // expected word on the unitig strand
                 // flank filter: foreign entries of the bucket are dropped without a sequence gather
-                cand[a] = e0 + a * kBlock < E && flank_ok(X, (uint32_t)off, k, w, (uint32_t)(ent[a] & 0xFFFFu)) && mm_pos >= off &&
+                cand[a] = e0 + a * SC::NT < E && flank_ok(X, (uint32_t)off, k, w, (uint32_t)(ent[a] & 0xFFFFu)) && mm_pos >= off &&
                           mm_pos - off <= last_km_start;
                 pp[a] = mm_pos - off;
                 kw[a] = cand[a] ? read_kmer_i(ix.seqbv, pp[a], k) : 0;
@@ -354,13 +375,13 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
             }
         }
     }
-    __syncthreads();
+    SC::sync();
     // ---- S4: heavy buckets go through the skew index (sshash.rs:415-433)
     if (S.cnt_skew != 0) { // uniform
         const uint32_t ns = S.cnt_skew;
-        __syncthreads();
+        SC::sync();
         if (ix.has_skew) {
-            for (uint32_t j = t; j < ns; j += kBlock) {
+            for (uint32_t j = t; j < ns; j += SC::NT) {
                 uint32_t i = S.list_b[j];
                 uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
                 S.slot[i] = fw < rc ? fw : rc;
@@ -368,9 +389,9 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
                 S.eoff[j] = i; // eoff is free now: remember the heavy items across the level loop
             }
             if (t == 0) { S.cnt_a = ns; S.cnt_b = 0; }
-            __syncthreads();
-            tile_mphf(S, ix.skew, false);
-            for (uint32_t j = t; j < ns; j += kBlock) {
+            SC::sync();
+            tile_mphf<SC>(S, ix.skew, false);
+            for (uint32_t j = t; j < ns; j += SC::NT) {
                 uint32_t i = S.eoff[j];
                 if (S.n[i] == kNMiss) continue;
                 uint64_t p = read_packed(ix.skew_pos, S.slot[i], ix.skew_pos_width);
@@ -379,12 +400,13 @@ __device__ __forceinline__ void tile_resolve(TileLds &S, const IndexView &ix) {
                 if (mt != MZ_NO_MATCH) S.best[i] = ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p;
             }
         }
-        __syncthreads();
+        SC::sync();
     }
 }
 
 // S5: answer of item i (any thread may ask for any item after tile_resolve)
-__device__ __forceinline__ mz_k2upos tile_result(const TileLds &S, const IndexView &ix, uint32_t i) {
+template <class SC>
+__device__ __forceinline__ mz_k2upos tile_result(const TileLdsT<SC::NT> &S, const IndexView &ix, uint32_t i) {
     unsigned long long b = S.best[i];
     if (b == kBestNone) return make_none();
     uint64_t p = b & ((1ull << kPosBits) - 1);
@@ -413,26 +435,66 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t base = tile * kTileQ;
         const uint32_t n_valid = (uint32_t)(n - base < (uint64_t)kTileQ ? n - base : (uint64_t)kTileQ);
-        tile_begin(S);
+        tile_begin<BlockScope>(S);
         // ---- S0: canonical encode + minimizer
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * kBlock + t;
             uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
             uint64_t rc = kmer_rc(fw, k);
-            tile_set_query(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
+            tile_set_query<BlockScope>(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
         }
-        tile_resolve(S, ix);
+        tile_resolve<BlockScope>(S, ix);
         // ---- S5: coalesced 16-byte stores
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * kBlock + t;
             bool act = i < n_valid;
-            mz_k2upos r = act ? tile_result(S, ix, i) : make_none();
+            mz_k2upos r = act ? tile_result<BlockScope>(S, ix, i) : make_none();
             if (act) out[base + i] = r;
             tally.add(act && r.match != MZ_NO_MATCH, act && r.match == MZ_NO_MATCH, false);
         }
         __syncthreads();
+    }
+    tally.flush(counts);
+}
+
+// Wave-scoped form of the same kernel: every wavefront owns a 256-query tile in its own LDS slice and walks the
+// stages on its own -- no workgroup barriers, so a wave waiting for its gathers never holds three others back.
+template <uint32_t KW>
+__global__ __launch_bounds__(kBlock) void k2u_wave_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
+                                                          mz_k2upos *__restrict__ out, mz_counts *counts) {
+    fix_kw<KW>(ix);
+    using SC = WaveScope;
+    constexpr int kWT = SC::NT * kQpt; // queries per wave tile
+    __shared__ TileLdsT<SC::NT> SS[kBlock / 64];
+    TileLdsT<SC::NT> &S = SS[threadIdx.x >> 6];
+    const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
+    const uint64_t kmask = kmer_mask(k);
+    const uint64_t n_tiles = (n + kWT - 1) / kWT;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (kBlock / 64);
+    Tally tally;
+    for (uint64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const uint64_t base = tile * kWT;
+        const uint32_t n_valid = (uint32_t)(n - base < (uint64_t)kWT ? n - base : (uint64_t)kWT);
+        tile_begin<SC>(S);
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * SC::NT + t;
+            uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
+            uint64_t rc = kmer_rc(fw, k);
+            tile_set_query<SC>(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
+        }
+        tile_resolve<SC>(S, ix);
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            uint32_t i = q * SC::NT + t;
+            bool act = i < n_valid;
+            mz_k2upos r = act ? tile_result<SC>(S, ix, i) : make_none();
+            if (act) out[base + i] = r;
+            tally.add(act && r.match != MZ_NO_MATCH, act && r.match == MZ_NO_MATCH, false);
+        }
+        SC::sync();
     }
     tally.flush(counts);
 }
@@ -448,19 +510,19 @@ __global__ __launch_bounds__(kBlock) void k2u_compact_kernel(IndexView ix, const
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t base = tile * kTileQ;
         const uint32_t n_valid = (uint32_t)(n - base < (uint64_t)kTileQ ? n - base : (uint64_t)kTileQ);
-        tile_begin(S);
+        tile_begin<BlockScope>(S);
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * kBlock + t;
             uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
             uint64_t rc = kmer_rc(fw, k);
-            tile_set_query(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
+            tile_set_query<BlockScope>(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
         }
-        tile_resolve(S, ix);
+        tile_resolve<BlockScope>(S, ix);
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * kBlock + t;
-            mz_k2upos r = i < n_valid ? tile_result(S, ix, i) : make_none();
+            mz_k2upos r = i < n_valid ? tile_result<BlockScope>(S, ix, i) : make_none();
             bool hit = r.match != MZ_NO_MATCH;
             unsigned long long b = __ballot(hit);
             unsigned lane = __lane_id();
@@ -564,7 +626,7 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
     Tally tally;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t B0 = tile * kTileQ;
-        tile_begin(S);
+        tile_begin<BlockScope>(S);
         if (t == 0) { // read holding the first base of the tile: largest r with read_offsets[r] <= B0
             uint64_t lo = 0, hi = n_reads;
             while (hi - lo > 1) {
@@ -624,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
                 rc = kmer_rc(fw, k);
                 if (query) mn = window_minimizer(R, i, fw, rc, k, w);
             }
-            tile_set_query(S, i, fw, mn, query);
+            tile_set_query<BlockScope>(S, i, fw, mn, query);
             if (state[q] == 1) { // non-ACGT window: reported, never queried
                 mz_k2upos sk = make_none();
                 sk.match = MZ_SKIPPED;
@@ -632,11 +694,11 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
             }
             tally.add(false, false, state[q] == 1);
         }
-        tile_resolve(S, ix);
+        tile_resolve<BlockScope>(S, ix);
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             const bool pend = state[q] == 2;
-            mz_k2upos res = pend ? tile_result(S, ix, q * kBlock + t) : make_none();
+            mz_k2upos res = pend ? tile_result<BlockScope>(S, ix, q * kBlock + t) : make_none();
             if (pend) out[out_idx[q]] = res;
             tally.add(pend && res.match != MZ_NO_MATCH, pend && res.match == MZ_NO_MATCH, false);
         }
@@ -662,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, uns
     unsigned n_k = 0, n_fail = 0, n_dup = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t P0 = tile * kPos;
-        tile_begin(S);
+        tile_begin<BlockScope>(S);
         if (t == 0) {
             uint64_t lo = 0, hi = ix.n_unitigs;
             while (hi - lo > 1) {
@@ -689,10 +751,10 @@ __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, uns
                 if (valid[q]) { fw = read_kmer_i(ix.seqbv, p, k); rc = kmer_rc(fw, k); }
             }
             Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
-            tile_set_query(S, i, fw, mn, valid[q]);          // km
-            tile_set_query(S, kPos + i, rc, mn, valid[q]);   // km.swap(): same canonical k-mer, same minimizer
+            tile_set_query<BlockScope>(S, i, fw, mn, valid[q]);          // km
+            tile_set_query<BlockScope>(S, kPos + i, rc, mn, valid[q]);   // km.swap(): same canonical k-mer, same minimizer
         }
-        tile_resolve(S, ix);
+        tile_resolve<BlockScope>(S, ix);
 #pragma unroll
         for (int q = 0; q < kPpt; ++q) {
             if (!valid[q]) continue;
@@ -700,7 +762,7 @@ __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, uns
             const uint64_t p = P0 + i;
             ++n_k;
             for (int o = 0; o < 2; ++o) {
-                mz_k2upos r = tile_result(S, ix, o ? kPos + i : i);
+                mz_k2upos r = tile_result<BlockScope>(S, ix, o ? kPos + i : i);
                 uint32_t want = o ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH;
                 bool ok = r.match == want && r.unitig_id == (uint32_t)ui[q] && r.pos == (uint32_t)(p - us[q]) &&
                           r.unitig_len == (uint32_t)(ue[q] - us[q]);
@@ -822,6 +884,10 @@ static bool use_v1_kernel() {
     static const bool v = [] { const char *e = getenv("MZ_K2U_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
     return v;
 }
+static bool use_wave_kernel() {
+    static const bool v = [] { const char *e = getenv("MZ_K2U_KERNEL"); return !e || e[0] != 't'; }(); // default; MZ_K2U_KERNEL=tile selects the workgroup-scoped form
+    return v;
+}
 
 int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
                      hipStream_t stream) {
@@ -833,6 +899,13 @@ int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_
     }
     if (use_v1_kernel()) { // lane-per-query kernel (kept for A/B measurements)
         hipLaunchKernelGGL(k2u_batch_kernel, dim3(grid_for(d, n, 32)), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
+    } else if (use_wave_kernel()) {
+        uint64_t n_blocks = (n + kTileQ - 1) / kTileQ; // four 256-query wave tiles per workgroup
+        unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_blocks, (uint64_t)d.n_cu * 4096));
+        if (d.view.k == 31 && d.view.w == 15)
+            hipLaunchKernelGGL(k2u_wave_kernel<kKW3115>, dim3(grid), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
+        else
+            hipLaunchKernelGGL(k2u_wave_kernel<0>, dim3(grid), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
     } else {
         uint64_t n_tiles = (n + kTileQ - 1) / kTileQ;
         static const unsigned gf = [] { const char *e = getenv("MZ_GRID_FACTOR"); int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 4096); }(); // one tile per workgroup measured best (gf 4..1000: 10.5..11.0 G/s)
