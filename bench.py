@@ -128,7 +128,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--validate", action="store_true", help="also run validate_self on the device before timing")
+    ap.add_argument("--no-validate", dest="validate", action="store_false",
+                    help="skip the correctness gate (K2U::validate_self on the device, every k-mer in both orientations) before timing")
     ap.add_argument("--host-build", action="store_true", help="build the index with the multi-threaded host builder instead of on the GPU")
     ap.add_argument("--mode", default="kmers", choices=["kmers", "reads"],
                     help="kmers: batched point queries (headline); reads: BASELINE config 3, every window of 150-bp reads "

@@ -375,3 +375,23 @@ def test_gpu_built_index_is_bit_identical_to_host_built(prefix, w, skew, tmp_pat
         diff = next(i for i in range(len(a)) if a[i] != b[i])
         raise AssertionError(f"index files differ first at byte {diff} of {len(a)}")
     dev.validate_self()
+
+
+def test_concurrent_host_threads_on_one_handle(yeast):
+    """kphf/mod.rs:105-109 requires Self: Sync: several host threads query one index concurrently (ctypes drops the GIL)"""
+    import threading
+    k, seqs = yeast
+    ix, orc, (words, total, starts) = both(seqs, k, 15, 16)
+    ix.to_device(0)
+    qs = [H.query_mix(words, starts, k, 150000 + 1000 * i, seed=100 + i) for i in range(6)]
+    wants = [orc.k2u_batch(q, n_threads=2)[0] for q in qs]
+    gots = [None] * len(qs)
+
+    def work(i):
+        for _ in range(3):
+            gots[i] = ix.k2u_batch(qs[i])[0]
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(qs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for g, w_ in zip(gots, wants):
+        assert g.tobytes() == w_.tobytes()
