@@ -193,17 +193,22 @@ __global__ __launch_bounds__(kB) void bef_overflow_kernel(const uint64_t *__rest
         blocks[j * 8] = off | (1ull << 63);
     }
 }
-// packed `pos` entries (PackedVec::assign of make_entry(pos, cls, flank)); words are pre-zeroed
-__global__ __launch_bounds__(kB) void pos_entries_kernel(const uint64_t *__restrict__ keys, uint64_t n, ScanParams P, uint32_t width, uint64_t *packed) {
+// packed `pos` entries (PackedVec::assign of make_entry(pos, cls, flank)): one lane per OUTPUT word, which gathers the
+// (at most three) entries overlapping it -- plain stores, no atomics on words shared by neighbouring lanes
+__global__ __launch_bounds__(kB) void pos_entries_kernel(const uint64_t *__restrict__ keys, uint64_t n, ScanParams P, uint32_t width, uint64_t n_words,
+                                                         uint64_t *__restrict__ packed) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
     const uint64_t pmask = (1ull << P.key_shift) - 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
-        const uint64_t key = keys[i], pc = key & pmask, pos = pc >> 1;
-        const uint64_t ent = make_entry(pos, (uint32_t)(pc & 1), flank_of(P.useq, P.total_len, pos, P.w));
-        const uint64_t b = i * width, wi = b >> 6;
-        const uint32_t sh = (uint32_t)(b & 63);
-        atomicOr((unsigned long long *)&packed[wi], ent << sh);
-        if (sh + width > 64) atomicOr((unsigned long long *)&packed[wi + 1], ent >> (64 - sh));
+    for (uint64_t wi = (uint64_t)blockIdx.x * kB + threadIdx.x; wi < n_words; wi += stride) {
+        const uint64_t bit0 = wi * 64;
+        uint64_t word = 0;
+        for (uint64_t i = bit0 / width; i < n && i * width < bit0 + 64; ++i) {
+            const uint64_t pc = keys[i] & pmask, pos = pc >> 1;
+            const uint64_t ent = make_entry(pos, (uint32_t)(pc & 1), flank_of(P.useq, P.total_len, pos, P.w));
+            const uint64_t b = i * width;
+            word |= b >= bit0 ? ent << (b - bit0) : ent >> (bit0 - b);
+        }
+        packed[wi] = word;
     }
 }
 
@@ -468,8 +473,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         const uint64_t n_words = (n_occ * h.pos.width + 63) / 64 + 2;
         uint64_t *d_packed = nullptr;
         BG_HIP(buf.alloc(&d_packed, n_words));
-        BG_HIP(hipMemset(d_packed, 0, n_words * 8));
-        hipLaunchKernelGGL(pos_entries_kernel, dim3(grid_of(n_occ)), dim3(kB), 0, 0, d_keys, n_occ, P, h.pos.width, d_packed);
+        hipLaunchKernelGGL(pos_entries_kernel, dim3(grid_of(n_words)), dim3(kB), 0, 0, d_keys, n_occ, P, h.pos.width, n_words, d_packed);
         if (int rc = download(h.pos.w, d_packed, n_words)) return rc;
         buf.release(d_packed);
     }
