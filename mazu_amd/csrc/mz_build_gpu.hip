@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kB) void finish_records_kernel(uint64_t *minrec, ui
         uint64_t *W = minrec + j * kMinRecWords;
         const uint64_t r0 = rank0[j];
         const uint32_t c = (uint32_t)counts[j];
-        W[0] = r0;
+        W[0] = minrec_header(r0, W[1], W[2], W[3]);
         W[8] = 1ull << 63;
         if (c == 0) continue;
         uint64_t xs[kBefSpan + 1], enc[8];
@@ -440,6 +440,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
     if (int rc = download(h.mm.blocks, d_minrec, n_rec * kMinRecWords)) return rc;
     buf.release(d_minrec); buf.release(d_rcnt); buf.release(d_rrank);
     phase("G3 minimizer records");
+    if (timing) std::fprintf(stderr, "[mz gpu build] %llu of %llu minimizer records overflow to the global offsets\n", (unsigned long long)h.n_minrec_overflow, (unsigned long long)n_rec);
 
     // global partitioned Elias-Fano over psum
     {

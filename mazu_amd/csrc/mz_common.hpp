@@ -100,7 +100,7 @@ MZ_HD uint64_t read_kmer(const uint64_t *words, uint64_t pos, uint32_t k) {
     uint64_t b = pos * 2, wi = b >> 6;
     uint32_t sh = (uint32_t)(b & 63);
     uint64_t lo = words[wi], hi = words[wi + 1];
-    uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    uint64_t x = (lo >> sh) | ((hi << 1) << (63 - sh)); // branch-free funnel shift (sh == 0: second term vanishes): both loads stay unconditional
     return x & kmer_mask(k);
 }
 
@@ -109,7 +109,7 @@ MZ_HD uint64_t read_packed(const uint64_t *words, uint64_t i, uint32_t width) {
     uint64_t b = i * width, wi = b >> 6;
     uint32_t sh = (uint32_t)(b & 63);
     uint64_t lo = words[wi], hi = words[wi + 1];
-    uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    uint64_t x = (lo >> sh) | ((hi << 1) << (63 - sh)); // branch-free funnel shift (sh == 0: second term vanishes): both loads stay unconditional
     return width >= 64 ? x : (x & ((1ull << width) - 1));
 }
 
@@ -220,12 +220,17 @@ struct BefView {
 };
 // decode elements t and t+1 of one 8-word block; returns false when the block is flagged as
 // overflowed and no overflow table is given (the caller then falls back to another structure)
+MZ_HD bool bef_decode_pair(const uint64_t (&L)[8], uint32_t t, const uint64_t *ovf, uint64_t &v0, uint64_t &v1);
 MZ_HD bool bef_block_pair(const uint64_t *b, uint32_t t, const uint64_t *ovf, uint64_t &v0, uint64_t &v1) {
     uint64_t L[8];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int j = 0; j < 8; ++j) L[j] = b[j];
+    return bef_decode_pair(L, t, ovf, v0, v1);
+}
+// the same from a block already held in registers
+MZ_HD bool bef_decode_pair(const uint64_t (&L)[8], uint32_t t, const uint64_t *ovf, uint64_t &v0, uint64_t &v1) {
     const uint64_t hdr = L[0];
     const uint64_t base = hdr & ((1ull << 40) - 1);
     if (hdr >> 63) { // overflow block: plain values
@@ -238,11 +243,39 @@ MZ_HD bool bef_block_pair(const uint64_t *b, uint32_t t, const uint64_t *ovf, ui
     const uint32_t l = (uint32_t)((hdr >> 40) & 63);
     // ones number t-1 (element t) and t (element t+1) of the unary high part; element 0 is the base
     uint32_t need = t == 0 ? 0 : t - 1; // index of the first one we need
-    uint32_t p_first = 0, p_second = 0, acc = 0;
-    bool got_first = false, got_second = false;
+    uint32_t p_first = 0, p_second = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
+    // straight-line form for the wavefront: running popcounts pick the word holding one number `need` (one in-word select),
+    // the following one is the next set bit of that word or the first set bit of the next non-empty word
+    {
+        uint32_t cum[8];
+        cum[0] = 0;
 #pragma unroll
-#endif
+        for (int j = 1; j < 8; ++j) cum[j] = cum[j - 1] + popc64(L[j]);
+        uint64_t word = L[1];
+        uint32_t prev = 0, wi = 0;
+        uint32_t nxt = 0;                           // first set bit after word wi, as a position in the 448-bit vector
+        uint32_t after[8];                          // after[j]: first set bit in words j+1..7
+        after[7] = 0;
+#pragma unroll
+        for (int j = 6; j >= 1; --j) after[j] = L[j + 1] ? (uint32_t)j * 64 + ctz64(L[j + 1]) : after[j + 1];
+        nxt = after[1];
+#pragma unroll
+        for (int j = 2; j < 8; ++j) {
+            const bool adv = cum[j - 1] <= need;
+            word = adv ? L[j] : word;
+            prev = adv ? cum[j - 1] : prev;
+            wi = adv ? (uint32_t)(j - 1) : wi;
+            nxt = adv ? after[j] : nxt;
+        }
+        const uint32_t bit = select_in_word(word, need - prev);
+        p_first = wi * 64 + bit;
+        const uint64_t rest = (word >> bit) >> 1;   // bits above `bit`
+        p_second = rest ? p_first + 1 + ctz64(rest) : nxt;
+    }
+#else
+    uint32_t acc = 0;
+    bool got_first = false, got_second = false;
     for (int j = 1; j < 8; ++j) {
         uint64_t word = L[j];
         uint32_t c = popc64(word);
@@ -258,6 +291,7 @@ MZ_HD bool bef_block_pair(const uint64_t *b, uint32_t t, const uint64_t *ovf, ui
         }
         acc += c;
     }
+#endif
     // low parts from the bit planes
     uint32_t lo_a = 0, lo_b = 0; // low part of element `need+1` and of the following element
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -336,19 +370,28 @@ struct IndexView {
 // would usually hand back a false-positive slot; and a member needs no second gather for its
 // bucket range (sshash.rs:482-483).  HBM fetches whole 128-byte lines, so the second half is free.
 constexpr uint32_t kMinRecKeysLog2 = 8, kMinRecWords = 16;
+// w0 = members before the record (40 bits) | members in bitmap word 1 << 40 | in words 1..2 << 48 | in words 1..3 << 56,
+// so a lookup reads w0 and the ONE bitmap word of its key
+constexpr uint64_t kMinRecRankMask = (1ull << 40) - 1;
+MZ_HD uint64_t minrec_header(uint64_t rank0, uint64_t w1, uint64_t w2, uint64_t w3) {
+    const uint64_t c1 = popc64(w1), c2 = c1 + popc64(w2), c3 = c2 + popc64(w3);
+    return rank0 | (c1 << 40) | (c2 << 48) | (c3 << 56);
+}
+// member test and rank inside the record from w0 and the bitmap word holding the key
+MZ_HD bool minrec_probe(uint64_t w0, uint64_t wv, uint32_t key, uint32_t &local) {
+    const uint32_t bit = key & ((1u << kMinRecKeysLog2) - 1), dw = bit >> 6, bi = bit & 63;
+    local = popc64(wv & ~(~0ull << bi)) + (dw ? (uint32_t)(w0 >> (32 + 8 * dw)) & 0xFFu : 0u);
+    return (wv >> bi) & 1;
+}
 MZ_HD bool direct_lookup(const uint64_t *blocks, uint64_t key, uint64_t &idx, uint32_t *local = nullptr) {
     const uint32_t x = (uint32_t)key;
     const uint64_t *b = blocks + (uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords;
-    const uint32_t bit = x & ((1u << kMinRecKeysLog2) - 1), dw = bit >> 6, bi = bit & 63;
-    const uint64_t base = b[0], w1 = b[1], w2 = b[2], w3 = b[3], w4 = b[4];
-    const uint64_t wv = dw == 0 ? w1 : dw == 1 ? w2 : dw == 2 ? w3 : w4;
-    uint32_t r = popc64(bi ? (wv & ((1ull << bi) - 1)) : 0);
-    if (dw > 0) r += popc64(w1);
-    if (dw > 1) r += popc64(w2);
-    if (dw > 2) r += popc64(w3);
-    idx = base + r;
+    const uint64_t w0 = b[0], wv = b[1 + ((x & ((1u << kMinRecKeysLog2) - 1)) >> 6)];
+    uint32_t r;
+    const bool member = minrec_probe(w0, wv, x, r);
+    idx = (w0 & kMinRecRankMask) + r;
     if (local) *local = r;
-    return (wv >> bi) & 1;
+    return member;
 }
 // member test + bucket id + bucket range from one record; `global` is the fallback for overflowed records
 MZ_HD bool minrec_lookup(const uint64_t *blocks, const BefView &global, uint64_t key, uint64_t &h, uint64_t &ps, uint64_t &pe) {
@@ -438,9 +481,10 @@ MZ_HD UnitigSpan locate_unitig(const uint64_t *bv_blocks, uint64_t pos) {
     return locate_unitig(bv_blocks + (pos >> kBvBasesPerBlockLog2) * 8, (uint32_t)(pos & (kBvBasesPerBlock - 1)),
                          pos & ~(uint64_t)(kBvBasesPerBlock - 1));
 }
-MZ_HD UnitigSpan locate_unitig(const uint64_t *b, uint32_t off, uint64_t base) {
-    uint64_t id0 = b[0], start0 = b[1], end_last = b[2];
-    uint64_t d[4] = {b[4], b[5], b[6], b[7]};
+// boundary block given by value: header (first unitig id, its start, end of the last unitig) + the four words of boundary bits
+MZ_HD UnitigSpan locate_unitig_w(uint64_t id0, uint64_t start0, uint64_t end_last, uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3,
+                                 uint32_t off, uint64_t base) {
+    uint64_t d[4] = {d0, d1, d2, d3};
     uint32_t wsel = off >> 6, bi = off & 63;
     uint64_t below_mask = bi ? ((1ull << bi) - 1) : 0;
     UnitigSpan s;
@@ -460,6 +504,9 @@ MZ_HD UnitigSpan locate_unitig(const uint64_t *b, uint32_t off, uint64_t base) {
     s.end = first_at >= 0 ? base + (uint64_t)first_at + 1 : end_last;
     return s;
 }
+MZ_HD UnitigSpan locate_unitig(const uint64_t *b, uint32_t off, uint64_t base) {
+    return locate_unitig_w(b[0], b[1], b[2], b[4], b[5], b[6], b[7], off, base);
+}
 
 
 // ---- interleaved sequence / boundary records (IndexView::seqbv) ----------------------------------------
@@ -469,7 +516,7 @@ MZ_HD uint64_t read_kmer_i(const uint64_t *rec, uint64_t pos, uint32_t k) {
     uint64_t b = pos * 2, wi = b >> 6;
     uint32_t sh = (uint32_t)(b & 63);
     uint64_t lo = seq_word_i(rec, wi), hi = seq_word_i(rec, wi + 1);
-    uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    uint64_t x = (lo >> sh) | ((hi << 1) << (63 - sh)); // branch-free funnel shift (sh == 0: second term vanishes): both loads stay unconditional
     return x & kmer_mask(k);
 }
 MZ_HD UnitigSpan locate_unitig_i(const uint64_t *rec, uint64_t pos) {

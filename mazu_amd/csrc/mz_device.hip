@@ -98,8 +98,40 @@ constexpr uint32_t kPosBits = 36;
 #define MZ_SPECULATE 1
 #endif
 constexpr bool kSpeculate = MZ_SPECULATE != 0;
+#ifndef MZ_STOP_AFTER
+#define MZ_STOP_AFTER 0 // stage-cost experiments only (tools/ab_build.sh): 1 = S0, 2 = S1/S2, 3 = S3, 4 = S4; results are then meaningless
+#endif
+constexpr int kStopAfter = MZ_STOP_AFTER;
 // S.n[i]: bucket size (< kNSkew), or one of the markers below (kNIdle: no query in this slot)
 constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu;
+// S.qinfo[i]: the flank16 an entry must show for item i (mz_common.hpp `pos` entry), in the orientation of the canonical
+// word g*: bits 0..7 = the 4 bases left of the minimizer in g*, bits 8..15 = the 4 bases right of it | offset << 16 |
+// kQMulti once a second bucket entry survived the flank filter
+constexpr uint32_t kQOffShift = 16, kQOffMask = 0x1Fu, kQMulti = 0x80000000u;
+__device__ __forceinline__ uint32_t query_flank(uint64_t g, uint32_t off, uint32_t w) {
+    const uint32_t ql = (uint32_t)(off >= kFlankBases ? g >> (2 * (off - kFlankBases)) : g << (2 * (kFlankBases - off))) & 0xFFu;
+    const uint32_t qr = (uint32_t)(g >> (2 * (off + w))) & 0xFFu;
+    return ql | (qr << 8);
+}
+// flank16 of an entry emitted on the reverse strand, brought into the orientation of g*: the 8 bases reversed and complemented
+__device__ __forceinline__ uint32_t flank_revcomp(uint32_t f) {
+    uint32_t x = __brev(f) >> 16;
+    x = ((x >> 1) & 0x5555u) | ((x & 0x5555u) << 1);
+    return x ^ 0xFFFFu;
+}
+
+// boundary half of a sequence+boundary record, fetched as four 16-byte loads (records are 128-byte aligned)
+struct SeqBoundary {
+    ulonglong2 h01, h23, d01, d23;
+};
+__device__ __forceinline__ SeqBoundary load_boundary(const uint64_t *seqbv, uint64_t pos) {
+    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(seqbv + (pos >> kBvBasesPerBlockLog2) * kSeqRecWords + 8);
+    return SeqBoundary{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ UnitigSpan locate_boundary(const SeqBoundary &b, uint64_t pos) {
+    return locate_unitig_w(b.h01.x, b.h01.y, b.h23.x, b.d01.x, b.d01.y, b.d23.x, b.d23.y, (uint32_t)(pos & (kBvBasesPerBlock - 1)),
+                           pos & ~(uint64_t)(kBvBasesPerBlock - 1));
+}
 
 // Execution scope of a tile: a whole 256-thread workgroup (barriers) or ONE wavefront (no barriers: the four
 // waves of a workgroup then run their own tiles independently and never wait for each other).
@@ -118,19 +150,24 @@ struct WaveScope {
 
 template <int NT>
 struct TileLdsT {
+    using ListT = typename std::conditional<(NT * kQpt <= 256), uint8_t, uint16_t>::type; // item indices of one tile
     uint64_t fw[NT * kQpt];               // forward word of the query
-    uint64_t slot[NT * kQpt];             // minimizer word -> bucket id h -> bucket start (skew: canonical word -> slot)
-    unsigned long long best[NT * kQpt];   // (bucket order key << 37) | (twin << 36) | global k-mer position
-    uint32_t n[NT * kQpt];                // bucket size, kNSkew, kNIdle or kNMiss
+    uint64_t slot[NT * kQpt];             // minimizer word -> bucket id h -> bucket start (skew: canonical word -> slot); after S5: unitig id << 32 | length
+    unsigned long long best[NT * kQpt];   // candidate: (bucket order << 37) | global k-mer position; after S5: 0 identity / 1 twin / kBestNone
+    uint32_t n[NT * kQpt];                // bucket size, kNSkew, kNIdle or kNMiss; after S5: offset of the k-mer in its unitig
     uint32_t eoff[NT * kQpt + 1];         // exclusive prefix sum of bucket sizes
-    uint16_t list_a[NT * kQpt], list_b[NT * kQpt];
-    uint8_t off[NT * kQpt];               // minimizer offset inside g*
+    uint32_t qinfo[NT * kQpt];            // expected flank16 of the query | minimizer offset inside g* << 16 | kQMulti
+    ListT list_a[NT * kQpt], list_b[NT * kQpt];
     uint32_t cnt_a, cnt_b, cnt_skew, wave_tot[NT / 64];
+#ifdef MZ_LDS_PAD
+    uint64_t pad[MZ_LDS_PAD * NT / 64];
+#endif
 };
 using TileLds = TileLdsT<kBlock>;
 
 // append `idx` of the lanes with pred to an LDS list (one LDS atomic per wave)
-__device__ __forceinline__ void wave_push(uint16_t *list, uint32_t *cnt, bool pred, uint32_t idx) {
+template <class T>
+__device__ __forceinline__ void wave_push(T *list, uint32_t *cnt, bool pred, uint32_t idx) {
     unsigned long long b = __ballot(pred);
     if (b == 0) return;
     unsigned lane = __lane_id();
@@ -138,7 +175,7 @@ __device__ __forceinline__ void wave_push(uint16_t *list, uint32_t *cnt, bool pr
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(cnt, (uint32_t)__popcll(b));
     base = __shfl(base, (int)leader);
-    if (pred) list[base + __popcll(b & ((1ull << lane) - 1))] = (uint16_t)idx;
+    if (pred) list[base + __popcll(b & ((1ull << lane) - 1))] = (T)idx;
 }
 
 struct MphfProbe { // one level: issue the loads first, evaluate later
@@ -192,7 +229,7 @@ __device__ __forceinline__ void tile_mphf(TileLdsT<SC::NT> &S, const MphfView &m
         }
         lv = 1;
     }
-    uint16_t *cur = S.list_a, *nxt = S.list_b;
+    typename TileLdsT<SC::NT>::ListT *cur = S.list_a, *nxt = S.list_b;
     uint32_t *ccur = &S.cnt_a, *cnxt = &S.cnt_b;
     uint32_t round = 0;
     for (;;) {
@@ -232,7 +269,7 @@ __device__ __forceinline__ void tile_mphf(TileLdsT<SC::NT> &S, const MphfView &m
         lv += nl;
         SC::sync();
         if (t == 0) *ccur = 0;
-        uint16_t *tl = cur; cur = nxt; nxt = tl;
+        auto *tl = cur; cur = nxt; nxt = tl;
         uint32_t *tc = ccur; ccur = cnxt; cnxt = tc;
     }
     SC::sync();
@@ -246,10 +283,10 @@ __device__ __forceinline__ void tile_begin(TileLdsT<SC::NT> &S) {
     if (SC::tid() == 0) { S.cnt_a = 0; S.cnt_b = 0; S.cnt_skew = 0; }
 }
 template <class SC>
-__device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, uint64_t fw, Minimizer mn, bool valid) {
+__device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, uint64_t fw, uint64_t rc, Minimizer mn, uint32_t w, bool valid) {
     S.fw[i] = fw;
     S.slot[i] = mn.word;
-    S.off[i] = (uint8_t)mn.offset;
+    S.qinfo[i] = query_flank(fw <= rc ? fw : rc, mn.offset, w) | (mn.offset << kQOffShift);
     S.best[i] = kBestNone;
     S.n[i] = valid ? 0u : kNIdle;
 }
@@ -258,26 +295,73 @@ template <class SC>
 __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexView &ix) {
     const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
     SC::sync();
+    if constexpr (kStopAfter == 1) return;
     // ---- S1: minimizer -> bucket id.  Direct-address rank bitmap (2w <= 32): one dense gather, no rounds;
     //          otherwise the BBHash level loop
     if (ix.mm.direct) {
-        // S1+S2 fused: member test, bucket id and bucket range from ONE 128-byte minimizer record
+        // S1+S2 fused: member test, bucket id and bucket range from ONE 128-byte minimizer record.  Straight-line and in
+        // two batches so that the gathers of all kQpt items of a lane are in flight together: (a) header + the bitmap word
+        // of the key, (b) the bucket-offset half of the same line.  Idle slots probe record 0 (always there).
+        uint32_t key[kQpt], local[kQpt];
+        uint64_t w0[kQpt], wv[kQpt];
+        const uint64_t *rec[kQpt];
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            uint32_t i = q * SC::NT + t;
-            bool heavy = false;
-            if (S.n[i] < kNIdle) {
-                uint64_t h, ps, pe;
-                if (minrec_lookup(ix.mm.blocks, ix.buckets, S.slot[i], h, ps, pe)) {
-                    uint64_t cnt = pe - ps;
-                    heavy = cnt > ix.skew_param;                    // sshash.rs:486-490
+            const uint32_t i = q * SC::NT + t;
+            key[q] = S.n[i] < kNIdle ? (uint32_t)S.slot[i] : 0u;
+            rec[q] = ix.mm.blocks + (uint64_t)(key[q] >> kMinRecKeysLog2) * kMinRecWords;
+            w0[q] = rec[q][0];
+            wv[q] = rec[q][1 + ((key[q] & ((1u << kMinRecKeysLog2) - 1)) >> 6)];
+        }
+        uint32_t slow = 0; // items whose record defers to the global offsets (0.15 % of the records at S-human)
+#pragma unroll
+        for (int q0 = 0; q0 < kQpt; q0 += 2) { // (b) two records at a time: 32 VGPRs of offsets in flight
+            uint64_t L[2][8];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(rec[q0 + qq] + 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const ulonglong2 x = v[j]; L[qq][2 * j] = x.x; L[qq][2 * j + 1] = x.y; }
+            }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = q0 + qq;
+                const uint32_t i = q * SC::NT + t;
+                const bool act = S.n[i] < kNIdle;
+                const bool member = minrec_probe(w0[q], wv[q], key[q], local[q]);
+                uint64_t ps = 0, pe = 0;
+                const bool ok = bef_decode_pair(L[qq], local[q] < kBefSpan ? local[q] : 0u, nullptr, ps, pe) && local[q] < kBefSpan;
+                bool heavy = false;
+                if (act) {
+                    if (!member) {
+                        S.n[i] = kNMiss;
+                    } else if (ok) {
+                        const uint64_t cnt = pe - ps;
+                        heavy = cnt > ix.skew_param;                        // sshash.rs:486-490
+                        S.slot[i] = ps;
+                        S.n[i] = heavy ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
+                    } else {
+                        slow |= 1u << q;
+                    }
+                }
+                wave_push(S.list_b, &S.cnt_skew, heavy, i);
+            }
+        }
+        if (__ballot(slow != 0)) {
+#pragma unroll
+            for (int q = 0; q < kQpt; ++q) {
+                const uint32_t i = q * SC::NT + t;
+                bool heavy = false;
+                if (slow & (1u << q)) {
+                    uint64_t ps, pe;
+                    bef_get_pair(ix.buckets, (w0[q] & kMinRecRankMask) + local[q], ps, pe);
+                    const uint64_t cnt = pe - ps;
+                    heavy = cnt > ix.skew_param;
                     S.slot[i] = ps;
                     S.n[i] = heavy ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
-                } else {
-                    S.n[i] = kNMiss;
                 }
+                wave_push(S.list_b, &S.cnt_skew, heavy, i);
             }
-            wave_push(S.list_b, &S.cnt_skew, heavy, i);
         }
     } else {
         tile_mphf<SC>(S, ix.mm, true);
@@ -299,83 +383,118 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
         }
     }
     SC::sync();
-    // ---- S3: flatten bucket entries (exclusive scan of n over the tile, blocked by thread)
+    if constexpr (kStopAfter == 2) return;
+    // ---- S3: bucket entries of the whole tile as ONE flat sequence (exclusive scan of the bucket sizes, items blocked by
+    //          thread), so lanes are busy whatever the bucket-size distribution.  Chunks of kEpt consecutive entries per lane;
+    //          the owner of an entry comes from a max-scan over "bucket head" marks (the item index, dropped at the slot of
+    //          its first entry): no per-entry search.
     {
-        uint32_t v[kQpt], sum = 0;
+        uint32_t nq[kQpt], eo[kQpt], sum = 0;
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            uint32_t nn = S.n[t * kQpt + q];
-            v[q] = sum;
-            sum += (nn >= kNSkew) ? 0u : nn;
+            const uint32_t nn = S.n[t * kQpt + q];
+            nq[q] = (nn >= kNSkew) ? 0u : nn;
+            eo[q] = sum;
+            sum += nq[q];
         }
         uint32_t incl = sum;
         for (int d = 1; d < 64; d <<= 1) {
             uint32_t o = __shfl_up(incl, d);
             if ((int)(t & 63) >= d) incl += o;
         }
-        if ((t & 63) == 63) S.wave_tot[t >> 6] = incl;
-        SC::sync();
+        if constexpr (SC::NT > 64) {
+            if ((t & 63) == 63) S.wave_tot[t >> 6] = incl;
+            SC::sync();
+        }
         uint32_t wbase = 0;
-        for (uint32_t wv = 0; wv < (t >> 6); ++wv) wbase += S.wave_tot[wv];
-        uint32_t excl = wbase + incl - sum;
+        if constexpr (SC::NT > 64)
+            for (uint32_t wv = 0; wv < (t >> 6); ++wv) wbase += S.wave_tot[wv];
+        const uint32_t excl = wbase + incl - sum;
 #pragma unroll
-        for (int q = 0; q < kQpt; ++q) S.eoff[t * kQpt + q] = excl + v[q];
+        for (int q = 0; q < kQpt; ++q) { eo[q] += excl; S.eoff[t * kQpt + q] = eo[q]; }
         if (t == SC::NT - 1) S.eoff[(SC::NT * kQpt)] = excl + sum;
-    }
-    SC::sync();
-    {
+        SC::sync();
         const uint32_t E = S.eoff[(SC::NT * kQpt)];
         const uint64_t last_km_start = ix.total_len - k;
-        constexpr int kEpt = 4; // entries in flight per lane: the `pos` gathers are issued together, then the sequence gathers
-        for (uint32_t e0 = t; e0 < E; e0 += SC::NT * kEpt) {
-            uint32_t own[kEpt], jdx[kEpt];
-            uint64_t ent[kEpt];
+        constexpr int kEpt = 4;                    // entries per lane and chunk, their `pos` gathers in flight together
+        constexpr uint32_t kChunk = SC::NT * kEpt; // == items per tile, so list_a can hold the marks
+        static_assert(kEpt == kQpt, "marks live in list_a");
+        uint32_t carry = 0;                        // owner of the entries before the first head of a chunk
+        for (uint32_t base = 0; base < E; base += kChunk) {
+#pragma unroll
+            for (int a = 0; a < kEpt; ++a) S.list_a[t * kEpt + a] = 0;
+            SC::sync();
+#pragma unroll
+            for (int q = 0; q < kQpt; ++q)
+                if (nq[q] != 0 && eo[q] >= base && eo[q] - base < kChunk) S.list_a[eo[q] - base] = (typename TileLdsT<SC::NT>::ListT)(t * kQpt + q);
+            SC::sync();
+            uint32_t own[kEpt];
 #pragma unroll
             for (int a = 0; a < kEpt; ++a) {
-                const uint32_t e = e0 + a * SC::NT;
-                own[a] = 0; jdx[a] = 0; ent[a] = 0;
-                if (e < E) {
-                    uint32_t lo = 0, hi = (SC::NT * kQpt); // owner item: largest i with eoff[i] <= e
-                    while (hi - lo > 1) {
-                        uint32_t mid = (lo + hi) >> 1;
-                        if (S.eoff[mid] <= e) lo = mid; else hi = mid;
-                    }
-                    own[a] = lo;
-                    jdx[a] = e - S.eoff[lo];
-                    ent[a] = read_packed(ix.pos, S.slot[lo] + jdx[a], ix.pos_width);           // sshash.rs:495
+                own[a] = S.list_a[t * kEpt + a];
+                if (a) own[a] = own[a] > own[a - 1] ? own[a] : own[a - 1];
+            }
+            uint32_t run = own[kEpt - 1]; // inclusive max-scan over lanes (item indices grow with the entry index)
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t o = __shfl_up(run, d);
+                if ((int)(t & 63) >= d && o > run) run = o;
+            }
+            uint32_t before = __shfl_up(run, 1);
+            if ((t & 63) == 0) before = 0;
+            uint32_t total = __shfl(run, 63);
+            if constexpr (SC::NT > 64) {
+                if ((t & 63) == 63) S.wave_tot[t >> 6] = run;
+                SC::sync();
+                total = 0;
+                for (uint32_t wv = 0; wv < SC::NT / 64; ++wv) {
+                    const uint32_t wt = S.wave_tot[wv];
+                    if (wv < (t >> 6) && wt > before) before = wt;
+                    if (wt > total) total = wt;
                 }
             }
-            uint64_t kw[kEpt], pp[kEpt];
-            bool cand[kEpt];
+            if (carry > before) before = carry;
+            if (carry < total) carry = total;
+            // owners back into the mark array, then entries are taken strided (lane t: base + a * NT + t) so that one gather
+            // instruction covers consecutive entries: entries of one bucket share their lines within ONE instruction
+#pragma unroll
+            for (int a = 0; a < kEpt; ++a) S.list_a[t * kEpt + a] = (typename TileLdsT<SC::NT>::ListT)(own[a] < before ? before : own[a]);
+            SC::sync();
+            uint32_t jdx[kEpt];
+            uint64_t ent[kEpt];
+#pragma unroll
+            for (int a = 0; a < kEpt; ++a) own[a] = S.list_a[a * SC::NT + t];
+            SC::sync(); // the mark array is rewritten by the next chunk
+#pragma unroll
+            for (int a = 0; a < kEpt; ++a) { // no branches: the kEpt gathers of a lane are in flight together (slots past E re-read entry E-1)
+                const uint32_t e = base + a * SC::NT + t;
+                const uint32_t ec = e < E ? e : E - 1;
+                if (e >= E) own[a] = carry;
+                jdx[a] = ec - S.eoff[own[a]];
+                ent[a] = read_packed(ix.pos, S.slot[own[a]] + jdx[a], ix.pos_width);               // sshash.rs:495
+            }
 #pragma unroll
             for (int a = 0; a < kEpt; ++a) {
+                if (base + a * SC::NT + t >= E) continue;
                 const uint32_t i = own[a];
                 const bool cls = (ent[a] >> kEntryFlankBits) & 1;
                 const uint64_t mm_pos = ent[a] >> kEntryShift;
-                const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                const uint64_t off_a = S.off[i];
-                const uint64_t off = cls ? k - off_a - w : off_a;                    // class 1: candidate B (:527), class 0: A (:498)
-                const uint64_t X = cls ? (fw <= rc ? rc : fw) : (fw <= rc ? fw : rc); // expected word on the unitig strand
+                const uint32_t qi = S.qinfo[i];
+                const uint32_t off_a = (qi >> kQOffShift) & kQOffMask, room = k - w - off_a;
+                const uint32_t off = cls ? room : off_a;                            // class 1: candidate B (:527), class 0: A (:498)
                 // flank filter: foreign entries of the bucket are dropped without a sequence gather
-                cand[a] = e0 + a * SC::NT < E && flank_ok(X, (uint32_t)off, k, w, (uint32_t)(ent[a] & 0xFFFFu)) && mm_pos >= off &&
-                          mm_pos - off <= last_km_start;
-                pp[a] = mm_pos - off;
-                kw[a] = cand[a] ? read_kmer_i(ix.seqbv, pp[a], k) : 0;
-            }
-#pragma unroll
-            for (int a = 0; a < kEpt; ++a) {
-                if (!cand[a]) continue;
-                const uint32_t i = own[a];
-                const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                const uint32_t mt = word_equivalency(fw, rc, kw[a]);
-                const uint64_t jj = jdx[a] < 0x7FFFFFFu ? jdx[a] : 0x7FFFFFFu;
-                // optimistic: the unitig-boundary check (:509-514) is done once, in tile_result
-                if (mt != MZ_NO_MATCH)
-                    atomicMin(&S.best[i], (jj << (kPosBits + 1)) | ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | pp[a]);
+                const uint32_t nl = off_a < kFlankBases ? off_a : kFlankBases, nr = room < kFlankBases ? room : kFlankBases;
+                const uint32_t mask = ((0xFFu << (2 * (kFlankBases - nl))) & 0xFFu) | (((1u << (2 * nr)) - 1) << 8);
+                const uint32_t fl = (uint32_t)(ent[a] & 0xFFFFu);
+                if ((((cls ? flank_revcomp(fl) : fl) ^ qi) & mask) != 0 || mm_pos < off || mm_pos - off > last_km_start) continue;
+                // the first survivor in bucket order is the item's candidate (verified in S5); a second one is only flagged
+                const uint64_t jj = jdx[a] < 0x3FFFFFFu ? jdx[a] : 0x3FFFFFFu;
+                const unsigned long long old = atomicMin(&S.best[i], (jj << (kPosBits + 1)) | (mm_pos - off));
+                if (old != kBestNone && !(qi & kQMulti)) S.qinfo[i] = qi | kQMulti;
             }
         }
     }
     SC::sync();
+    if constexpr (kStopAfter == 3) return;
     // ---- S4: heavy buckets go through the skew index (sshash.rs:415-433)
     if (S.cnt_skew != 0) { // uniform
         const uint32_t ns = S.cnt_skew;
@@ -394,25 +513,72 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
             for (uint32_t j = t; j < ns; j += SC::NT) {
                 uint32_t i = S.eoff[j];
                 if (S.n[i] == kNMiss) continue;
-                uint64_t p = read_packed(ix.skew_pos, S.slot[i], ix.skew_pos_width);
-                uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                uint32_t mt = word_equivalency(fw, rc, read_kmer_i(ix.seqbv, p, k));
-                if (mt != MZ_NO_MATCH) S.best[i] = ((uint64_t)(mt == MZ_TWIN_MATCH) << kPosBits) | p;
+                S.best[i] = read_packed(ix.skew_pos, S.slot[i], ix.skew_pos_width); // the one candidate of a heavy item
             }
         }
         SC::sync();
     }
+    if constexpr (kStopAfter == 4) return;
+    // ---- S5: every item has at most one recorded candidate position.  ONE gather of its 128-byte sequence+boundary record
+    //          verifies the k-mer (sshash.rs:500-504) and yields unitig id / offset / length (:509-514); the answer is parked
+    //          in the item's own slot[] / n[] words, which are dead by now.  Candidates are compacted first, so the gathers
+    //          are issued by full waves, two records in flight per lane.
+#pragma unroll
+    for (int q = 0; q < kQpt; ++q) {
+        uint32_t i = q * SC::NT + t;
+        wave_push(S.list_a, &S.cnt_a, S.best[i] != kBestNone, i);
+    }
+    SC::sync();
+    {
+        const uint32_t nc = S.cnt_a;
+        constexpr int kCpt = 2;
+        for (uint32_t j0 = t; j0 < ((nc + SC::NT - 1) / SC::NT) * SC::NT; j0 += SC::NT * kCpt) {
+            uint32_t ci[kCpt];
+            uint64_t cp[kCpt], kw[kCpt];
+            SeqBoundary bd[kCpt];
+            bool act[kCpt];
+#pragma unroll
+            for (int a = 0; a < kCpt; ++a) { // no branches: idle slots read the record of position 0
+                const uint32_t j = j0 + a * SC::NT;
+                act[a] = j < nc;
+                ci[a] = S.list_a[act[a] ? j : 0u];
+                cp[a] = act[a] ? S.best[ci[a]] & ((1ull << kPosBits) - 1) : 0ull;
+                kw[a] = read_kmer_i(ix.seqbv, cp[a], k);
+                bd[a] = load_boundary(ix.seqbv, cp[a]);
+            }
+#pragma unroll
+            for (int a = 0; a < kCpt; ++a) {
+                if (!act[a]) continue;
+                const uint32_t i = ci[a];
+                const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+                const uint32_t mt = word_equivalency(fw, rc, kw[a]);
+                const UnitigSpan sp = locate_boundary(bd[a], cp[a]);
+                mz_k2upos r = make_none();
+                if (mt != MZ_NO_MATCH && cp[a] + k <= sp.end) r = make_hit(sp, cp[a], mt);
+                else if (S.qinfo[i] & kQMulti) r = lookup(ix, fw); // more than one survivor and the first one failed: exact in-order rescan
+                if (r.match != MZ_NO_MATCH) {
+                    S.slot[i] = ((uint64_t)r.unitig_id << 32) | r.unitig_len;
+                    S.n[i] = r.pos;
+                    S.best[i] = r.match == MZ_TWIN_MATCH ? 1ull : 0ull;
+                } else {
+                    S.best[i] = kBestNone;
+                }
+            }
+        }
+    }
+    SC::sync();
+    if (t == 0) S.cnt_a = 0;
 }
 
-// S5: answer of item i (any thread may ask for any item after tile_resolve)
+// answer of item i (any thread may ask for any item after tile_resolve)
 template <class SC>
 __device__ __forceinline__ mz_k2upos tile_result(const TileLdsT<SC::NT> &S, const IndexView &ix, uint32_t i) {
-    unsigned long long b = S.best[i];
+    (void)ix;
+    const unsigned long long b = S.best[i];
+    if constexpr (kStopAfter != 0) return mz_k2upos{(uint32_t)S.slot[i], S.n[i], (uint32_t)b, MZ_NO_MATCH};
     if (b == kBestNone) return make_none();
-    uint64_t p = b & ((1ull << kPosBits) - 1);
-    UnitigSpan s = locate_unitig_i(ix.seqbv, p);
-    if (p + ix.k <= s.end) return make_hit(s, p, ((b >> kPosBits) & 1) ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH);
-    return lookup(ix, S.fw[i]); // first verified candidate straddles two unitigs (sshash.rs:509-514): exact in-order rescan
+    const uint64_t s = S.slot[i];
+    return mz_k2upos{(uint32_t)(s >> 32), S.n[i], (uint32_t)s, b ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH};
 }
 
 // KW: compile-time (k << 8 | w) for the common configuration (constant shifts, masks and trip counts;
@@ -442,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
             uint32_t i = q * kBlock + t;
             uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
             uint64_t rc = kmer_rc(fw, k);
-            tile_set_query<BlockScope>(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
+            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), w, i < n_valid);
         }
         tile_resolve<BlockScope>(S, ix);
         // ---- S5: coalesced 16-byte stores
@@ -462,7 +628,7 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
 // Wave-scoped form of the same kernel: every wavefront owns a 256-query tile in its own LDS slice and walks the
 // stages on its own -- no workgroup barriers, so a wave waiting for its gathers never holds three others back.
 template <uint32_t KW>
-__global__ __launch_bounds__(kBlock) void k2u_wave_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
+__global__ __launch_bounds__(kBlock, 4) void k2u_wave_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
                                                           mz_k2upos *__restrict__ out, mz_counts *counts) {
     fix_kw<KW>(ix);
     using SC = WaveScope;
@@ -478,12 +644,18 @@ __global__ __launch_bounds__(kBlock) void k2u_wave_kernel(IndexView ix, const ui
         const uint64_t base = tile * kWT;
         const uint32_t n_valid = (uint32_t)(n - base < (uint64_t)kWT ? n - base : (uint64_t)kWT);
         tile_begin<SC>(S);
+        uint64_t fwq[kQpt];
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) { // all query words of the lane in flight together
+            const uint32_t i = q * SC::NT + t;
+            fwq[q] = fw_words[base + (i < n_valid ? i : 0u)];
+        }
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            uint32_t i = q * SC::NT + t;
-            uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
-            uint64_t rc = kmer_rc(fw, k);
-            tile_set_query<SC>(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
+            const uint32_t i = q * SC::NT + t;
+            const uint64_t fw = i < n_valid ? (fwq[q] & kmask) : 0;
+            const uint64_t rc = kmer_rc(fw, k);
+            tile_set_query<SC>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), w, i < n_valid);
         }
         tile_resolve<SC>(S, ix);
 #pragma unroll
@@ -516,7 +688,7 @@ __global__ __launch_bounds__(kBlock) void k2u_compact_kernel(IndexView ix, const
             uint32_t i = q * kBlock + t;
             uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
             uint64_t rc = kmer_rc(fw, k);
-            tile_set_query<BlockScope>(S, i, fw, canonical_minimizer(fw, rc, k, w, ix.seed), i < n_valid);
+            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), w, i < n_valid);
         }
         tile_resolve<BlockScope>(S, ix);
 #pragma unroll
@@ -686,7 +858,7 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
                 rc = kmer_rc(fw, k);
                 if (query) mn = window_minimizer(R, i, fw, rc, k, w);
             }
-            tile_set_query<BlockScope>(S, i, fw, mn, query);
+            tile_set_query<BlockScope>(S, i, fw, rc, mn, w, query);
             if (state[q] == 1) { // non-ACGT window: reported, never queried
                 mz_k2upos sk = make_none();
                 sk.match = MZ_SKIPPED;
@@ -751,8 +923,8 @@ __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, uns
                 if (valid[q]) { fw = read_kmer_i(ix.seqbv, p, k); rc = kmer_rc(fw, k); }
             }
             Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
-            tile_set_query<BlockScope>(S, i, fw, mn, valid[q]);          // km
-            tile_set_query<BlockScope>(S, kPos + i, rc, mn, valid[q]);   // km.swap(): same canonical k-mer, same minimizer
+            tile_set_query<BlockScope>(S, i, fw, rc, mn, w, valid[q]);          // km
+            tile_set_query<BlockScope>(S, kPos + i, rc, fw, mn, w, valid[q]);   // km.swap(): same canonical k-mer, same minimizer
         }
         tile_resolve<BlockScope>(S, ix);
 #pragma unroll

@@ -315,8 +315,9 @@ int Mphf::build_direct(const uint64_t *keys, uint64_t n, uint32_t key_bits, int 
     });
     uint64_t run = 0;
     for (uint64_t j = 0; j < nr; ++j) {
-        B[j * kMinRecWords] = run;
-        for (int q = 1; q <= 4; ++q) run += popc64(B[j * kMinRecWords + q]);
+        const uint64_t *W = B + j * kMinRecWords;
+        B[j * kMinRecWords] = minrec_header(run, W[1], W[2], W[3]);
+        for (int q = 1; q <= 4; ++q) run += popc64(W[q]);
         B[j * kMinRecWords + 8] = 1ull << 63; // bucket-offset half: "consult the global structure" until fill_bucket_offsets()
     }
     if (run != n) {
@@ -338,7 +339,7 @@ uint64_t Mphf::fill_bucket_offsets(const uint64_t *psum, uint64_t n_psum, int n_
             uint32_t c = 0;
             for (int q = 1; q <= 4; ++q) c += popc64(W[q]);
             if (c == 0) continue;
-            uint64_t rank0 = W[0];
+            uint64_t rank0 = W[0] & kMinRecRankMask;
             bool ok = c <= kBefSpan && rank0 + c < n_psum && bef_encode_block(psum + rank0, c, W + 8);
             if (!ok) { W[8] = 1ull << 63; OV[t]++; }
         }
@@ -811,7 +812,7 @@ uint64_t SSHashHost::num_bits() const {
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '5'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '6'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>
