@@ -138,14 +138,14 @@ __global__ __launch_bounds__(kB) void set_member_bits_kernel(const uint64_t *__r
     uint64_t stride = (uint64_t)gridDim.x * kB;
     for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
         uint32_t x = (uint32_t)words[i], bit = x & ((1u << kMinRecKeysLog2) - 1);
-        atomicOr((unsigned long long *)&minrec[(uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords + 1 + (bit >> 6)], 1ull << (bit & 63));
+        atomicOr((unsigned long long *)&minrec[(uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords + minrec_bitmap_word(bit >> 6)], 1ull << (bit & 63));
     }
 }
 __global__ __launch_bounds__(kB) void record_counts_kernel(const uint64_t *__restrict__ minrec, uint64_t n_rec, uint64_t *__restrict__ counts) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
     for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < n_rec; j += stride) {
         const uint64_t *W = minrec + j * kMinRecWords;
-        counts[j] = popc64(W[1]) + popc64(W[2]) + popc64(W[3]) + popc64(W[4]);
+        counts[j] = minrec_members(W);
     }
 }
 // ranks + Elias-Fano half of every minimizer record (Mphf::build_direct + fill_bucket_offsets of the host)
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kB) void finish_records_kernel(uint64_t *minrec, ui
         uint64_t *W = minrec + j * kMinRecWords;
         const uint64_t r0 = rank0[j];
         const uint32_t c = (uint32_t)counts[j];
-        W[0] = minrec_header(r0, W[1], W[2], W[3]);
+        minrec_set_headers(W, r0);
         W[8] = 1ull << 63;
         if (c == 0) continue;
         uint64_t xs[kBefSpan + 1], enc[8];
@@ -470,7 +470,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
     // packed pos entries
     {
         h.pos.n = n_occ;
-        h.pos.width = bit_len(make_entry(us.total_len, 1, 0xFFFF));
+        h.pos.width = kPosEntryBits;
         const uint64_t n_words = (n_occ * h.pos.width + 63) / 64 + 2;
         uint64_t *d_packed = nullptr;
         BG_HIP(buf.alloc(&d_packed, n_words));

@@ -360,8 +360,8 @@ struct IndexView {
 // ---- structure probes (used by both sides) -------------------------------------------
 // Direct-address monotone MPHF + bucket offsets in ONE 128-byte line ("minimizer record"), used when
 // the key universe is small (w-mers with 2w <= 32 bits).  Record r covers keys [256r, 256r+256):
-//   first 64 bytes : w0 = members before this record (== bucket id of its first member),
-//                    w1..w4 = one bit per key, set for members
+//   first 64 bytes : four pairs {header, 64 keys of the membership bitmap}; header = members before this record
+//                    (== bucket id of its first member) | members in the earlier pairs << 40
 //   second 64 bytes: a partitioned-Elias-Fano block (bef_block_pair) with the bucket starts of this
 //                    record's members, psum[w0 .. w0+64]; flagged "overflow" if the record holds more
 //                    than 64 members or does not fit -- then the global BlockedEF is consulted.
@@ -370,26 +370,32 @@ struct IndexView {
 // would usually hand back a false-positive slot; and a member needs no second gather for its
 // bucket range (sshash.rs:482-483).  HBM fetches whole 128-byte lines, so the second half is free.
 constexpr uint32_t kMinRecKeysLog2 = 8, kMinRecWords = 16;
-// w0 = members before the record (40 bits) | members in bitmap word 1 << 40 | in words 1..2 << 48 | in words 1..3 << 56,
-// so a lookup reads w0 and the ONE bitmap word of its key
+// First half as four 16-byte pairs {header_j, bitmap word j} (j = key bits 6..7), so a lookup is ONE 16-byte load:
+// header_j = members before the record (40 bits) | members in bitmap words < j, inside the record << 40.
 constexpr uint64_t kMinRecRankMask = (1ull << 40) - 1;
-MZ_HD uint64_t minrec_header(uint64_t rank0, uint64_t w1, uint64_t w2, uint64_t w3) {
-    const uint64_t c1 = popc64(w1), c2 = c1 + popc64(w2), c3 = c2 + popc64(w3);
-    return rank0 | (c1 << 40) | (c2 << 48) | (c3 << 56);
+MZ_HD uint32_t minrec_bitmap_word(uint32_t j) { return 2 * j + 1; }
+// writes the four headers of a record whose bitmap words are in place
+MZ_HD void minrec_set_headers(uint64_t *W, uint64_t rank0) {
+    uint64_t c = 0;
+    for (uint32_t j = 0; j < 4; ++j) {
+        W[2 * j] = rank0 | (c << 40);
+        c += popc64(W[2 * j + 1]);
+    }
 }
-// member test and rank inside the record from w0 and the bitmap word holding the key
-MZ_HD bool minrec_probe(uint64_t w0, uint64_t wv, uint32_t key, uint32_t &local) {
-    const uint32_t bit = key & ((1u << kMinRecKeysLog2) - 1), dw = bit >> 6, bi = bit & 63;
-    local = popc64(wv & ~(~0ull << bi)) + (dw ? (uint32_t)(w0 >> (32 + 8 * dw)) & 0xFFu : 0u);
+MZ_HD uint32_t minrec_members(const uint64_t *W) { return popc64(W[1]) + popc64(W[3]) + popc64(W[5]) + popc64(W[7]); }
+// member test and rank inside the record from the pair of the key
+MZ_HD bool minrec_probe(uint64_t hdr, uint64_t wv, uint32_t key, uint32_t &local) {
+    const uint32_t bi = key & 63;
+    local = popc64(wv & ~(~0ull << bi)) + (uint32_t)(hdr >> 40);
     return (wv >> bi) & 1;
 }
 MZ_HD bool direct_lookup(const uint64_t *blocks, uint64_t key, uint64_t &idx, uint32_t *local = nullptr) {
     const uint32_t x = (uint32_t)key;
-    const uint64_t *b = blocks + (uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords;
-    const uint64_t w0 = b[0], wv = b[1 + ((x & ((1u << kMinRecKeysLog2) - 1)) >> 6)];
+    const uint64_t *b = blocks + (uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords + 2 * ((x & ((1u << kMinRecKeysLog2) - 1)) >> 6);
+    const uint64_t hdr = b[0], wv = b[1];
     uint32_t r;
-    const bool member = minrec_probe(w0, wv, x, r);
-    idx = (w0 & kMinRecRankMask) + r;
+    const bool member = minrec_probe(hdr, wv, x, r);
+    idx = (hdr & kMinRecRankMask) + r;
     if (local) *local = r;
     return member;
 }
@@ -532,6 +538,7 @@ MZ_HD UnitigSpan locate_unitig_i(const uint64_t *rec, uint64_t pos) {
 // (at least 4 flank bases are always covered: min(4,off) + min(4,k-w-off) >= 4 when k-w >= 4).
 // Entries that pass are verified against the 2-bit sequence exactly as in sshash.rs:500-504.
 constexpr uint32_t kFlankBases = 4, kEntryFlankBits = 4 * kFlankBases, kEntryShift = kEntryFlankBits + 1;
+constexpr uint32_t kPosEntryBits = 64; // stored width of an entry: whole words, so a gather is one aligned 8-byte load that never crosses a line
 MZ_HD uint64_t make_entry(uint64_t pos, uint32_t cls, uint32_t flank16) { return (pos << kEntryShift) | ((uint64_t)cls << kEntryFlankBits) | flank16; }
 MZ_HD uint32_t flank_of(const uint64_t *useq, uint64_t total_len, uint64_t pos, uint32_t w) {
     uint32_t f = 0;
@@ -599,7 +606,7 @@ MZ_HD mz_k2upos lookup_with_minimizer(const IndexView &ix, uint64_t fw, uint64_t
         // forward-canonical k-mer, so only candidate A (:498) can be a true occurrence; class 1:
         // reverse-canonical, only candidate B (:527).  The other candidate of the reference loop
         // can never verify ("strand class bit"), so skipping it keeps results identical.
-        uint64_t ent = read_packed(ix.pos, pi, ix.pos_width);
+        uint64_t ent = ix.pos[pi];
         const bool cls = (ent >> kEntryFlankBits) & 1;
         uint64_t mm_pos = ent >> kEntryShift, off = cls ? off_b : off_a;
         // expected word on the unitig strand: g* for class 0, its reverse complement for class 1

@@ -102,6 +102,13 @@ constexpr bool kSpeculate = MZ_SPECULATE != 0;
 #define MZ_STOP_AFTER 0 // stage-cost experiments only (tools/ab_build.sh): 1 = S0, 2 = S1/S2, 3 = S3, 4 = S4; results are then meaningless
 #endif
 constexpr int kStopAfter = MZ_STOP_AFTER;
+#ifndef MZ_REC_BATCH
+#define MZ_REC_BATCH 1
+#endif
+#ifndef MZ_WAVES_PER_EU
+#define MZ_WAVES_PER_EU 4
+#endif
+constexpr int kRecBatch = MZ_REC_BATCH; // minimizer records in flight per lane (S1)
 // S.n[i]: bucket size (< kNSkew), or one of the markers below (kNIdle: no query in this slot)
 constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu;
 // S.qinfo[i]: the flank16 an entry must show for item i (mz_common.hpp `pos` entry), in the orientation of the canonical
@@ -300,35 +307,33 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     //          otherwise the BBHash level loop
     if (ix.mm.direct) {
         // S1+S2 fused: member test, bucket id and bucket range from ONE 128-byte minimizer record.  Straight-line and in
-        // two batches so that the gathers of all kQpt items of a lane are in flight together: (a) header + the bitmap word
-        // of the key, (b) the bucket-offset half of the same line.  Idle slots probe record 0 (always there).
+        // two batches so that the gathers of all kQpt items of a lane are in flight together: (a) the {header, bitmap word}
+        // pair of the key, ONE 16-byte load, (b) the bucket-offset half of the same line.  Idle slots probe record 0 (always there).
         uint32_t key[kQpt], local[kQpt];
-        uint64_t w0[kQpt], wv[kQpt];
-        const uint64_t *rec[kQpt];
-#pragma unroll
-        for (int q = 0; q < kQpt; ++q) {
-            const uint32_t i = q * SC::NT + t;
-            key[q] = S.n[i] < kNIdle ? (uint32_t)S.slot[i] : 0u;
-            rec[q] = ix.mm.blocks + (uint64_t)(key[q] >> kMinRecKeysLog2) * kMinRecWords;
-            w0[q] = rec[q][0];
-            wv[q] = rec[q][1 + ((key[q] & ((1u << kMinRecKeysLog2) - 1)) >> 6)];
-        }
+        uint64_t w0[kQpt];
         uint32_t slow = 0; // items whose record defers to the global offsets (0.15 % of the records at S-human)
 #pragma unroll
-        for (int q0 = 0; q0 < kQpt; q0 += 2) { // (b) two records at a time: 32 VGPRs of offsets in flight
-            uint64_t L[2][8];
+        for (int q0 = 0; q0 < kQpt; q0 += kRecBatch) { // kRecBatch whole records in flight per lane
+            uint64_t wv[kRecBatch], L[kRecBatch][8];
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(rec[q0 + qq] + 8);
+            for (int qq = 0; qq < kRecBatch; ++qq) {
+                const int q = q0 + qq;
+                const uint32_t i = q * SC::NT + t;
+                key[q] = S.n[i] < kNIdle ? (uint32_t)S.slot[i] : 0u;
+                const uint64_t *rec = ix.mm.blocks + (uint64_t)(key[q] >> kMinRecKeysLog2) * kMinRecWords;
+                const ulonglong2 pr = *reinterpret_cast<const ulonglong2 *>(rec + 2 * ((key[q] & ((1u << kMinRecKeysLog2) - 1)) >> 6));
+                w0[q] = pr.x;
+                wv[qq] = pr.y;
+                const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(rec + 8);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const ulonglong2 x = v[j]; L[qq][2 * j] = x.x; L[qq][2 * j + 1] = x.y; }
             }
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
+            for (int qq = 0; qq < kRecBatch; ++qq) {
                 const int q = q0 + qq;
                 const uint32_t i = q * SC::NT + t;
                 const bool act = S.n[i] < kNIdle;
-                const bool member = minrec_probe(w0[q], wv[q], key[q], local[q]);
+                const bool member = minrec_probe(w0[q], wv[qq], key[q], local[q]);
                 uint64_t ps = 0, pe = 0;
                 const bool ok = bef_decode_pair(L[qq], local[q] < kBefSpan ? local[q] : 0u, nullptr, ps, pe) && local[q] < kBefSpan;
                 bool heavy = false;
@@ -470,7 +475,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 const uint32_t ec = e < E ? e : E - 1;
                 if (e >= E) own[a] = carry;
                 jdx[a] = ec - S.eoff[own[a]];
-                ent[a] = read_packed(ix.pos, S.slot[own[a]] + jdx[a], ix.pos_width);               // sshash.rs:495
+                ent[a] = ix.pos[S.slot[own[a]] + jdx[a]];                                           // sshash.rs:495
             }
 #pragma unroll
             for (int a = 0; a < kEpt; ++a) {
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
 // Wave-scoped form of the same kernel: every wavefront owns a 256-query tile in its own LDS slice and walks the
 // stages on its own -- no workgroup barriers, so a wave waiting for its gathers never holds three others back.
 template <uint32_t KW>
-__global__ __launch_bounds__(kBlock, 4) void k2u_wave_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
+__global__ __launch_bounds__(kBlock, MZ_WAVES_PER_EU) void k2u_wave_kernel(IndexView ix, const uint64_t *__restrict__ fw_words, uint64_t n,
                                                           mz_k2upos *__restrict__ out, mz_counts *counts) {
     fix_kw<KW>(ix);
     using SC = WaveScope;

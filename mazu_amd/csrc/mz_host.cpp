@@ -310,14 +310,14 @@ int Mphf::build_direct(const uint64_t *keys, uint64_t n, uint32_t key_bits, int 
     parallel_for(n_threads, n, [=](int, uint64_t b, uint64_t e) {
         for (uint64_t i = b; i < e; ++i) {
             uint32_t x = (uint32_t)keys[i], bit = x & ((1u << kMinRecKeysLog2) - 1);
-            __atomic_fetch_or(&B[(uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords + 1 + (bit >> 6)], 1ull << (bit & 63), __ATOMIC_RELAXED);
+            __atomic_fetch_or(&B[(uint64_t)(x >> kMinRecKeysLog2) * kMinRecWords + minrec_bitmap_word(bit >> 6)], 1ull << (bit & 63), __ATOMIC_RELAXED);
         }
     });
     uint64_t run = 0;
     for (uint64_t j = 0; j < nr; ++j) {
-        const uint64_t *W = B + j * kMinRecWords;
-        B[j * kMinRecWords] = minrec_header(run, W[1], W[2], W[3]);
-        for (int q = 1; q <= 4; ++q) run += popc64(W[q]);
+        uint64_t *W = B + j * kMinRecWords;
+        minrec_set_headers(W, run);
+        run += minrec_members(W);
         B[j * kMinRecWords + 8] = 1ull << 63; // bucket-offset half: "consult the global structure" until fill_bucket_offsets()
     }
     if (run != n) {
@@ -336,8 +336,7 @@ uint64_t Mphf::fill_bucket_offsets(const uint64_t *psum, uint64_t n_psum, int n_
     parallel_for(n_threads, nr, [=](int t, uint64_t b, uint64_t e) {
         for (uint64_t j = b; j < e; ++j) {
             uint64_t *W = B + j * kMinRecWords;
-            uint32_t c = 0;
-            for (int q = 1; q <= 4; ++q) c += popc64(W[q]);
+            uint32_t c = minrec_members(W);
             if (c == 0) continue;
             uint64_t rank0 = W[0] & kMinRecRankMask;
             bool ok = c <= kBefSpan && rank0 + c < n_psum && bef_encode_block(psum + rank0, c, W + 8);
@@ -715,7 +714,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
                     PV[d++] = make_entry(O[j].pos >> 1, (uint32_t)(O[j].pos & 1), flank_of(useq, total_len_, O[j].pos >> 1, w));
             }
         });
-        max_pos = make_entry(us.total_len, 1, 0xFFFF);
+        max_pos = ~0ull; // entries are stored as whole 64-bit words: one aligned 8-byte load each (kPosEntryBits)
     }
     phase("scatter + flanks");
     // 6. skew index (sshash.rs:221-296): k-mers around every occurrence of a heavy minimizer
@@ -812,7 +811,7 @@ uint64_t SSHashHost::num_bits() const {
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '6'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '7'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>
@@ -863,7 +862,7 @@ int SSHashHost::load(const std::string &path) {
     uint32_t hs = 0;
     bool ok = get(f, us.k) && get(f, w) && get(f, seed) && get(f, skew_param) && get(f, us.total_len) && get(f, us.n_unitigs) &&
               get(f, n_minimizers) && get(f, hs) && getv(f, us.useq) && getv(f, us.starts) && getv(f, us.bv_blocks) &&
-              get_ef(f, us.accum_lens) && get_mphf(f, mm) && get(f, buckets.n) && get(f, buckets.n_overflow) && getv(f, buckets.blocks) && getv(f, buckets.ovf) && get_pv(f, pos);
+              get_ef(f, us.accum_lens) && get_mphf(f, mm) && get(f, buckets.n) && get(f, buckets.n_overflow) && getv(f, buckets.blocks) && getv(f, buckets.ovf) && get_pv(f, pos) && pos.width == kPosEntryBits;
     has_skew = hs != 0;
     if (ok && has_skew) ok = get_mphf(f, skew) && get_pv(f, skew_pos);
     if (ok) us.build_seqbv();
