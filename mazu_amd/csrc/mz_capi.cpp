@@ -229,8 +229,9 @@ int mz_sshash_k2u_batch_compact_device(mz_sshash *ix, const uint64_t *d_fw_words
 // chunk size of the host-pointer pipeline: 16 MB of queries / 32 MB of results per slot stay cache-resident on the host
 // (1 M: 1.41, 2 M: 1.48, 4 M: 1.26, 8 M: 1.01 G k-mers/s end to end; MZ_HOST_CHUNK overrides)
 static uint64_t host_chunk_queries() {
-    static const uint64_t c = [] { const char *e = std::getenv("MZ_HOST_CHUNK"); long long v = e ? atoll(e) : 0; return (uint64_t)(v > 0 ? v : (2ll << 20)); }();
-    return c;
+    const char *e = std::getenv("MZ_HOST_CHUNK"); // read per call: tests shrink it to walk the multi-chunk path
+    long long v = e ? atoll(e) : 0;
+    return (uint64_t)(v > 0 ? v : (2ll << 20));
 }
 // copies with a few host threads (one memcpy stream is ~10 GB/s, the PCIe link wants ~50)
 static void parallel_copy(void *dst, const void *src, uint64_t bytes) {

@@ -377,6 +377,23 @@ def test_gpu_built_index_is_bit_identical_to_host_built(prefix, w, skew, tmp_pat
     dev.validate_self()
 
 
+def test_host_pointer_batch_walks_several_chunks(yeast, monkeypatch):
+    """mz_sshash_k2u_batch pipelines chunks through two pinned slots: odd chunk size, partial last chunk, 1 and 2 chunks"""
+    k, seqs = yeast
+    ix, orc, (words, total, starts) = both(seqs, k, 15, 16)
+    ix.to_device(0)
+    q = H.query_mix(words, starts, k, 50_001, seed=77)
+    want, wc = orc.k2u_batch(q, n_threads=2)
+    for chunk in (4097, 25_000, 50_001, 50_000):
+        monkeypatch.setenv("MZ_HOST_CHUNK", str(chunk))
+        got, counts = ix.k2u_batch(q)
+        assert got.tobytes() == want.tobytes(), chunk
+        assert list(counts)[:2] == [int((want["match"] != 0).sum()), int((want["match"] == 0).sum())], chunk
+    monkeypatch.delenv("MZ_HOST_CHUNK")
+    got, _ = ix.k2u_batch(q[:1])
+    assert got.tobytes() == want[:1].tobytes()
+
+
 def test_concurrent_host_threads_on_one_handle(yeast):
     """kphf/mod.rs:105-109 requires Self: Sync: several host threads query one index concurrently (ctypes drops the GIL)"""
     import threading
