@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--w", type=int, default=15)
     ap.add_argument("--skew", type=int, default=32)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--neg-kind", default="uniform", choices=["uniform", "sub1"],
+                    help="negatives: NEG-U uniform words (the headline) or NEG-1 positives with one substituted base")
     ap.add_argument("--neg-frac", type=float, default=0.5, help="fraction of NEG-U negatives in the query mix (the metric is quoted at 0.5)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,7 +209,7 @@ def main():
     if args.mode == "reads":
         return bench_reads(args, ix, us, dev, rank, world, D)
     # ---- this rank's shard of the query batch, generated in HBM
-    q = synth.make_query_mix(ix, us, batch, seed=1000 + rank, device=dev, neg_frac=args.neg_frac)
+    q = synth.make_query_mix(ix, us, batch, seed=1000 + rank, device=dev, neg_frac=args.neg_frac, neg_kind=args.neg_kind)
     out = torch.empty(batch * 2, dtype=torch.int64, device=dev)
     counts = torch.zeros(3, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -244,7 +246,7 @@ def main():
         achieved = batch * B_ALG / avg_kernel_s / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.exists(tf) and args.neg_frac == 0.5:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload/batch only)
+        if os.path.exists(tf) and args.neg_frac == 0.5 and args.neg_kind == "uniform":  # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload/batch only)
             rec = json.load(open(tf)).get(f"{args.workload}:{batch}")
             traffic = rec["hbm_bytes_per_launch"] if rec else None
         res = {
@@ -253,7 +255,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: synthetic GRCh38-shaped unitig set, SSHash k=31 m={args.w} skew_param={args.skew}, "
-                                   f"{batch} queries/GPU/step, {100 - round(100 * args.neg_frac)}/{round(100 * args.neg_frac)} positive/negative",
+                                   f"{batch} queries/GPU/step, {100 - round(100 * args.neg_frac)}/{round(100 * args.neg_frac)} positive/negative" + ("" if args.neg_kind == "uniform" else " (NEG-1 negatives)"),
                        "total_len_bp": us["total_len"], "n_unitigs": us["n_unitigs"], "n_kmers": ix.n_kmers(),
                        "queries_per_gpu_per_step": batch, "index_hbm_gb": round(ix.device_bytes() / 1e9, 3),
                        "parallelism": f"index replicated x{n_gpus}, queries sharded, all-reduce(hit counts)"},

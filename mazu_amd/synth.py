@@ -84,21 +84,30 @@ def sample_positive_positions(starts, k, n, generator):
     return r + u * (k - 1)
 
 
-def make_query_mix(sshash, us, n, seed, device, neg_frac=0.5):
+def make_query_mix(sshash, us, n, seed, device, neg_frac=0.5, neg_kind="uniform"):
     """n forward words on `device`: (1-neg_frac) positives drawn through the index's own packed
-    sequence (random orientation), neg_frac NEG-U negatives (uniform 2k-bit words), shuffled.
-    Needs a GPU (positives are extracted by the HIP kernel)."""
+    sequence (random orientation), neg_frac negatives, shuffled.  neg_kind "uniform" = NEG-U (uniform
+    2k-bit words), "sub1" = NEG-1 (a positive with one substituted base: usually shares the minimizer
+    and the flanks, so it reaches the k-mer verification).  Needs a GPU (positives are extracted by the HIP kernel)."""
     dev = torch.device(device)
     g = _gen(dev, seed)
     k = us["k"]
     n_neg = int(n * neg_frac)
     n_pos = n - n_neg
     starts = us["starts"].to(dev)
-    pos = sample_positive_positions(starts, k, n_pos, g)
-    flip = torch.randint(0, 2, (n_pos,), generator=g, device=dev, dtype=torch.uint8)
     q = torch.empty(n, dtype=torch.int64, device=dev)
-    sshash.extract_kmers_device(pos, flip, q[:n_pos])
-    q[n_pos:] = torch.randint(0, 2 ** (2 * k), (n_neg,), generator=g, device=dev, dtype=torch.int64)
+    n_draw = n if neg_kind == "sub1" else n_pos
+    pos = sample_positive_positions(starts, k, n_draw, g)
+    flip = torch.randint(0, 2, (n_draw,), generator=g, device=dev, dtype=torch.uint8)
+    sshash.extract_kmers_device(pos, flip, q[:n_draw])
+    if neg_kind == "sub1":
+        base = torch.randint(0, k, (n_neg,), generator=g, device=dev, dtype=torch.int64)
+        delta = torch.randint(1, 4, (n_neg,), generator=g, device=dev, dtype=torch.int64)
+        q[n_pos:] ^= delta << (2 * base)
+    elif neg_kind == "uniform":
+        q[n_pos:] = torch.randint(0, 2 ** (2 * k), (n_neg,), generator=g, device=dev, dtype=torch.int64)
+    else:
+        raise ValueError(neg_kind)
     torch.cuda.synchronize(dev)
     perm = torch.randperm(n, generator=g, device=dev)
     return q[perm].contiguous()
