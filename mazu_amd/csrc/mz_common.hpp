@@ -517,17 +517,27 @@ MZ_HD UnitigSpan locate_unitig(const uint64_t *b, uint32_t off, uint64_t base) {
 
 // ---- interleaved sequence / boundary records (IndexView::seqbv) ----------------------------------------
 constexpr uint32_t kSeqRecWords = 16;
-MZ_HD uint64_t seq_word_i(const uint64_t *rec, uint64_t wi) { return rec[(wi >> 3) * kSeqRecWords + (wi & 7)]; }
+// Record r holds the 256 bases [224 r, 224 r + 256) and their boundary block: consecutive records overlap by 32 bases,
+// so a k-mer (k <= 31) starting at any position lies inside ONE record (r = pos / 224) and its verification never costs
+// a second line.  224 bases = 7 words, so the base words of record r are words 7r .. 7r+7 of the packed sequence.
+constexpr uint32_t kSeqRecStride = 224, kSeqRecStrideWords = kSeqRecStride / 32;
+MZ_HD uint64_t seq_rec_of(uint64_t pos, uint32_t &off) { // positions are < 2^36 (kPosBits)
+    const uint32_t r = (uint32_t)(pos >> 5) / kSeqRecStrideWords;
+    off = (uint32_t)(pos - (uint64_t)r * kSeqRecStride);
+    return r;
+}
 MZ_HD uint64_t read_kmer_i(const uint64_t *rec, uint64_t pos, uint32_t k) {
-    uint64_t b = pos * 2, wi = b >> 6;
-    uint32_t sh = (uint32_t)(b & 63);
-    uint64_t lo = seq_word_i(rec, wi), hi = seq_word_i(rec, wi + 1);
-    uint64_t x = (lo >> sh) | ((hi << 1) << (63 - sh)); // branch-free funnel shift (sh == 0: second term vanishes): both loads stay unconditional
+    uint32_t off;
+    const uint64_t *R = rec + seq_rec_of(pos, off) * kSeqRecWords;
+    const uint32_t wi = off >> 5, sh = 2 * (off & 31); // off <= 223: wi + 1 <= 7
+    const uint64_t lo = R[wi], hi = R[wi + 1];
+    const uint64_t x = (lo >> sh) | ((hi << 1) << (63 - sh)); // branch-free funnel shift (sh == 0: second term vanishes): both loads stay unconditional
     return x & kmer_mask(k);
 }
 MZ_HD UnitigSpan locate_unitig_i(const uint64_t *rec, uint64_t pos) {
-    return locate_unitig(rec + (pos >> kBvBasesPerBlockLog2) * kSeqRecWords + 8, (uint32_t)(pos & (kBvBasesPerBlock - 1)),
-                         pos & ~(uint64_t)(kBvBasesPerBlock - 1));
+    uint32_t off;
+    const uint64_t r = seq_rec_of(pos, off);
+    return locate_unitig(rec + r * kSeqRecWords + 8, off, r * kSeqRecStride);
 }
 
 // ---- `pos` entry: (minimizer position << 17) | (strand class << 16) | flank16 ---------------------

@@ -132,12 +132,14 @@ struct SeqBoundary {
     ulonglong2 h01, h23, d01, d23;
 };
 __device__ __forceinline__ SeqBoundary load_boundary(const uint64_t *seqbv, uint64_t pos) {
-    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(seqbv + (pos >> kBvBasesPerBlockLog2) * kSeqRecWords + 8);
+    uint32_t off;
+    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(seqbv + seq_rec_of(pos, off) * kSeqRecWords + 8);
     return SeqBoundary{v[0], v[1], v[2], v[3]};
 }
 __device__ __forceinline__ UnitigSpan locate_boundary(const SeqBoundary &b, uint64_t pos) {
-    return locate_unitig_w(b.h01.x, b.h01.y, b.h23.x, b.d01.x, b.d01.y, b.d23.x, b.d23.y, (uint32_t)(pos & (kBvBasesPerBlock - 1)),
-                           pos & ~(uint64_t)(kBvBasesPerBlock - 1));
+    uint32_t off;
+    const uint64_t r = seq_rec_of(pos, off);
+    return locate_unitig_w(b.h01.x, b.h01.y, b.h23.x, b.d01.x, b.d01.y, b.d23.x, b.d23.y, off, r * kSeqRecStride);
 }
 
 // Execution scope of a tile: a whole 256-thread workgroup (barriers) or ONE wavefront (no barriers: the four

@@ -406,12 +406,37 @@ int UnitigSet::finish() {
 
 // interleave the packed sequence and the boundary blocks into 128-byte records (IndexView::seqbv)
 void UnitigSet::build_seqbv() {
-    uint64_t nb = bv_blocks.size() / 8, nw = useq.size();
-    uint64_t nr = std::max<uint64_t>(nb, (nw + 7) / 8) + 1;
+    const uint64_t nr = (total_len + kSeqRecStride - 1) / kSeqRecStride + 1; // + a tail record: never probed by a valid position
     seqbv.assign(nr * kSeqRecWords, 0);
-    for (uint64_t wi = 0; wi < nw; ++wi) seqbv[(wi >> 3) * kSeqRecWords + (wi & 7)] = useq[wi];
-    for (uint64_t b = 0; b < nb; ++b)
-        for (int q = 0; q < 8; ++q) seqbv[b * kSeqRecWords + 8 + q] = bv_blocks[b * 8 + q];
+    const uint64_t nw = useq.size();
+    uint64_t uid = 0; // unitig holding the first base of the current record
+    for (uint64_t r = 0; r < nr; ++r) {
+        uint64_t *W = seqbv.data() + r * kSeqRecWords;
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint64_t wi = r * kSeqRecStrideWords + j;
+            W[j] = wi < nw ? useq[wi] : 0;
+        }
+        const uint64_t first = r * kSeqRecStride;
+        if (first >= total_len) {
+            W[8] = n_unitigs; W[9] = total_len; W[10] = total_len;
+            continue;
+        }
+        const uint64_t lastb = std::min<uint64_t>(first + kBvBasesPerBlock - 1, total_len - 1);
+        while (starts[uid + 1] <= first) ++uid;
+        uint64_t ul = uid; // -> the unitig holding the last base of the record
+        while (starts[ul + 1] <= lastb) { // every unitig that ends inside the record: bit at its last base (unitig_set.rs:90-93)
+            const uint64_t o = starts[ul + 1] - 1 - first;
+            W[12 + (o >> 6)] |= 1ull << (o & 63);
+            ++ul;
+        }
+        if (starts[ul + 1] - 1 == lastb) { // its own last base is the last base of the record
+            const uint64_t o = lastb - first;
+            W[12 + (o >> 6)] |= 1ull << (o & 63);
+        }
+        W[8] = uid;
+        W[9] = starts[uid];
+        W[10] = starts[ul + 1];
+    }
 }
 
 int UnitigSet::from_packed(const uint64_t *words, uint64_t total_len_, const uint64_t *starts_, uint64_t n, uint32_t k_) {
