@@ -538,7 +538,10 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     SC::sync();
     {
         const uint32_t nc = S.cnt_a;
-        constexpr int kCpt = 2;
+#ifndef MZ_CPT
+#define MZ_CPT 2
+#endif
+        constexpr int kCpt = MZ_CPT; // candidate records in flight per lane
         for (uint32_t j0 = t; j0 < ((nc + SC::NT - 1) / SC::NT) * SC::NT; j0 += SC::NT * kCpt) {
             uint32_t ci[kCpt];
             uint64_t cp[kCpt], kw[kCpt];
