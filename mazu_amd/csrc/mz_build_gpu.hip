@@ -75,6 +75,8 @@ __global__ __launch_bounds__(kB) void scan_minimizers_kernel(ScanParams P, uint6
                                                              unsigned long long *counter) {
     __shared__ uint64_t hf[kT + 32], hr[kT + 32];
     __shared__ uint64_t keys[kT];
+    __shared__ uint32_t s_wtot[kB / 64];
+    __shared__ unsigned long long s_base;
     const uint32_t t = threadIdx.x, k = P.k, w = P.w, n_win = k - w + 1;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t P0 = tile * kT;
@@ -111,18 +113,34 @@ __global__ __launch_bounds__(kB) void scan_minimizers_kernel(ScanParams P, uint6
             keys[i] = key;
         }
         __syncthreads();
+        // compaction: ONE global atomic per tile (a same-address atomic costs ~12 ns; one per wave and slice was 0.47 s at
+        // S-human), waves take consecutive ranges of the tile's reservation
+        unsigned long long bal[kQ];
+        uint32_t wave_total = 0;
 #pragma unroll
         for (int q = 0; q < kQ; ++q) {
             const uint32_t i = q * kB + t;
             const uint64_t key = keys[i];
             const bool emit = key != ~0ull && (i == 0 || keys[i - 1] != key);
-            unsigned long long b = __ballot(emit);
-            if (b) {
-                unsigned lane = __lane_id(), leader = (unsigned)(__ffsll((long long)b) - 1);
-                unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(b));
-                base = __shfl(base, (int)leader);
-                if (STORE && emit) out_keys[base + __popcll(b & ((1ull << lane) - 1))] = key;
+            bal[q] = __ballot(emit);
+            wave_total += (uint32_t)__popcll(bal[q]);
+        }
+        const unsigned lane = __lane_id(), wave = t >> 6;
+        if (lane == 0) s_wtot[wave] = wave_total;
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long tot = 0;
+            for (uint32_t wv = 0; wv < kB / 64; ++wv) tot += s_wtot[wv];
+            s_base = tot ? atomicAdd(counter, tot) : 0ull;
+        }
+        __syncthreads();
+        if (STORE) {
+            unsigned long long base = s_base;
+            for (uint32_t wv = 0; wv < wave; ++wv) base += s_wtot[wv];
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                if ((bal[q] >> lane) & 1) out_keys[base + __popcll(bal[q] & ((1ull << lane) - 1))] = keys[q * kB + t];
+                base += (unsigned long long)__popcll(bal[q]);
             }
         }
         __syncthreads();
