@@ -373,6 +373,17 @@ int UnitigSet::finish() {
             set_error("UnitigSet: unitig %llu is empty or offsets not increasing", (unsigned long long)i);
             return MZ_EINVAL;
         }
+    // mz_k2upos carries unitig id, offset and length as 32-bit fields; positions take 36 bits in the device tiles
+    if (n_unitigs > 0xFFFFFFFFull || total_len >= (1ull << 36)) {
+        set_error("UnitigSet: %llu unitigs / %llu bases exceed the 2^32 unitigs / 2^36 bases this build addresses",
+                  (unsigned long long)n_unitigs, (unsigned long long)total_len);
+        return MZ_EINVAL;
+    }
+    for (uint64_t i = 0; i < n_unitigs; ++i)
+        if (starts[i + 1] - starts[i] > 0xFFFFFFFFull) {
+            set_error("UnitigSet: unitig %llu is longer than 2^32-1 bases", (unsigned long long)i);
+            return MZ_EINVAL;
+        }
     // accum_lens as Elias-Fano (unitig_set.rs:98), plus the blocked boundary vector
     int rc = accum_lens.build(starts.data(), n_unitigs + 1, starts[n_unitigs]);
     if (rc != MZ_OK) return rc;
