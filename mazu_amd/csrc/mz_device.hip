@@ -800,15 +800,19 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
                                                            mz_k2upos *__restrict__ out, mz_counts *counts) {
     fix_kw<KW>(ix);
     using H = typename std::conditional<(KW != 0 && (KW & 255u) <= 16u), uint32_t, uint64_t>::type;
-    __shared__ TileLds S;
+    // bases and w-mer hashes are staged by the workgroup (1024 positions + the k-1 tail); the lookups of each 256-position
+    // quarter then run wave-scoped, like k2u_wave_kernel: no workgroup barrier inside tile_resolve
+    using SC = WaveScope;
+    __shared__ TileLdsT<SC::NT> SS[kBlock / 64];
     __shared__ ReadsLds<H> R;
     const uint32_t k = ix.k, w = ix.w, n_win = k - w + 1;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    TileLdsT<SC::NT> &S = SS[wave];
     const uint64_t n_tiles = (n_bases + kTileQ - 1) / kTileQ;
     Tally tally;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t B0 = tile * kTileQ;
-        tile_begin<BlockScope>(S);
+        tile_begin<SC>(S);
         if (t == 0) { // read holding the first base of the tile: largest r with read_offsets[r] <= B0
             uint64_t lo = 0, hi = n_reads;
             while (hi - lo > 1) {
@@ -848,7 +852,8 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
         uint64_t r = R.read0;
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            const uint32_t i = q * kBlock + t;
+            const uint32_t it = q * SC::NT + lane;               // item inside the wave's tile
+            const uint32_t i = wave * (SC::NT * kQpt) + it;      // position inside the workgroup's 1024
             const uint64_t b = B0 + i;
             state[q] = 0;
             out_idx[q] = 0;
@@ -868,7 +873,7 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
                 rc = kmer_rc(fw, k);
                 if (query) mn = window_minimizer(R, i, fw, rc, k, w);
             }
-            tile_set_query<BlockScope>(S, i, fw, rc, mn, w, query);
+            tile_set_query<SC>(S, it, fw, rc, mn, w, query);
             if (state[q] == 1) { // non-ACGT window: reported, never queried
                 mz_k2upos sk = make_none();
                 sk.match = MZ_SKIPPED;
@@ -876,11 +881,11 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
             }
             tally.add(false, false, state[q] == 1);
         }
-        tile_resolve<BlockScope>(S, ix);
+        tile_resolve<SC>(S, ix);
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             const bool pend = state[q] == 2;
-            mz_k2upos res = pend ? tile_result<BlockScope>(S, ix, q * kBlock + t) : make_none();
+            mz_k2upos res = pend ? tile_result<SC>(S, ix, q * SC::NT + lane) : make_none();
             if (pend) out[out_idx[q]] = res;
             tally.add(pend && res.match != MZ_NO_MATCH, pend && res.match == MZ_NO_MATCH, false);
         }
