@@ -895,38 +895,40 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
 }
 
 // ------------------------------------------------------------------------------------
-// K: validate_self on the device (kphf/mod.rs:69-139).  One tile = kTileQ/2 consecutive global base
-// positions, each queried as km (items 0..) and km.swap() (items kTileQ/2..) through the tile
+// K: validate_self on the device (kphf/mod.rs:69-139).  One wave tile = 128 consecutive global base
+// positions, each queried as km (items 0..127) and km.swap() (items 128..255) through the tile
 // machinery; the expected (unitig, offset, length) comes from the plain `starts` array, which the
 // lookup path never reads.
 // ------------------------------------------------------------------------------------
 template <uint32_t KW>
-__global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, unsigned long long *report) {
+__global__ __launch_bounds__(kBlock, 4) void validate_self_kernel(IndexView ix, unsigned long long *report) {
     fix_kw<KW>(ix);
-    __shared__ TileLds S;
-    __shared__ uint64_t s_uid0;
-    constexpr int kPos = kTileQ / 2, kPpt = kQpt / 2;
-    const uint32_t t = threadIdx.x, k = ix.k, w = ix.w;
+    using SC = WaveScope; // every wavefront validates its own 128 positions (256 items), like k2u_wave_kernel
+    __shared__ TileLdsT<SC::NT> SS[kBlock / 64];
+    TileLdsT<SC::NT> &S = SS[threadIdx.x >> 6];
+    constexpr int kPos = SC::NT * kQpt / 2, kPpt = kQpt / 2;
+    const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
     const uint64_t n_tiles = (ix.total_len + kPos - 1) / kPos;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (kBlock / 64);
     unsigned n_k = 0, n_fail = 0, n_dup = 0;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (uint64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
         const uint64_t P0 = tile * kPos;
-        tile_begin<BlockScope>(S);
-        if (t == 0) {
+        tile_begin<SC>(S);
+        uint64_t u = 0;
+        if (t == 0) { // unitig holding the first position of the tile
             uint64_t lo = 0, hi = ix.n_unitigs;
             while (hi - lo > 1) {
                 uint64_t mid = (lo + hi) >> 1;
                 if (ix.starts[mid] <= P0) lo = mid; else hi = mid;
             }
-            s_uid0 = lo;
+            u = lo;
         }
-        __syncthreads();
+        u = (uint64_t)__shfl((unsigned long long)u, 0);
         uint64_t ui[kPpt], us[kPpt], ue[kPpt];
         bool valid[kPpt];
-        uint64_t u = s_uid0;
 #pragma unroll
         for (int q = 0; q < kPpt; ++q) {
-            const uint32_t i = q * kBlock + t;
+            const uint32_t i = q * SC::NT + t;
             const uint64_t p = P0 + i;
             valid[q] = false;
             ui[q] = us[q] = ue[q] = 0;
@@ -938,18 +940,18 @@ __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, uns
                 if (valid[q]) { fw = read_kmer_i(ix.seqbv, p, k); rc = kmer_rc(fw, k); }
             }
             Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
-            tile_set_query<BlockScope>(S, i, fw, rc, mn, w, valid[q]);          // km
-            tile_set_query<BlockScope>(S, kPos + i, rc, fw, mn, w, valid[q]);   // km.swap(): same canonical k-mer, same minimizer
+            tile_set_query<SC>(S, i, fw, rc, mn, w, valid[q]);          // km
+            tile_set_query<SC>(S, kPos + i, rc, fw, mn, w, valid[q]);   // km.swap(): same canonical k-mer, same minimizer
         }
-        tile_resolve<BlockScope>(S, ix);
+        tile_resolve<SC>(S, ix);
 #pragma unroll
         for (int q = 0; q < kPpt; ++q) {
             if (!valid[q]) continue;
-            const uint32_t i = q * kBlock + t;
+            const uint32_t i = q * SC::NT + t;
             const uint64_t p = P0 + i;
             ++n_k;
             for (int o = 0; o < 2; ++o) {
-                mz_k2upos r = tile_result<BlockScope>(S, ix, o ? kPos + i : i);
+                mz_k2upos r = tile_result<SC>(S, ix, o ? kPos + i : i);
                 uint32_t want = o ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH;
                 bool ok = r.match == want && r.unitig_id == (uint32_t)ui[q] && r.pos == (uint32_t)(p - us[q]) &&
                           r.unitig_len == (uint32_t)(ue[q] - us[q]);
@@ -966,7 +968,7 @@ __global__ __launch_bounds__(kBlock) void validate_self_kernel(IndexView ix, uns
                 }
             }
         }
-        __syncthreads();
+        SC::sync();
     }
     for (int off = 32; off > 0; off >>= 1) {
         n_k += __shfl_down(n_k, off);
@@ -1139,7 +1141,7 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
 
 int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, hipStream_t stream) {
     MZ_HIP_CHECK(hipSetDevice(d.device));
-    uint64_t n_tiles = (d.view.total_len + kTileQ / 2 - 1) / (kTileQ / 2);
+    uint64_t n_tiles = ((d.view.total_len + 64 * kQpt / 2 - 1) / (64 * kQpt / 2) + kBlock / 64 - 1) / (kBlock / 64); // four wave tiles per workgroup
     if (d.view.k == 31 && d.view.w == 15)
         hipLaunchKernelGGL(validate_self_kernel<kKW3115>, dim3(tile_grid(d, n_tiles, 16)), dim3(kBlock), 0, stream, d.view,
                            (unsigned long long *)d_report);
