@@ -183,8 +183,30 @@ __global__ __launch_bounds__(kB) void finish_records_kernel(uint64_t *minrec, ui
             for (uint32_t q = 0; q <= c; ++q) xs[q] = psum[r0 + q];
             ok = bef_encode_block(xs, c, enc);
         }
-        if (ok) for (int q = 0; q < 8; ++q) W[8 + q] = enc[q];
-        else atomicAdd(n_overflow, 1ull);
+        if (ok) {
+            enc[0] |= minrec_filter_header(enc[0], xs[c] - xs[0]);
+            for (int q = 0; q < 8; ++q) W[8 + q] = enc[q];
+        } else {
+            atomicAdd(n_overflow, 1ull);
+        }
+    }
+}
+// negative filters of the records (Mphf::fill_filters of the host): one lane per minimizer walks its light bucket
+__global__ __launch_bounds__(kB) void record_filters_kernel(uint64_t *minrec, const uint64_t *__restrict__ words, uint64_t n_mm, const uint64_t *__restrict__ psum,
+                                                            const uint64_t *__restrict__ entries, uint64_t skew_param) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n_mm; i += stride) {
+        const uint64_t ps = psum[i], pe = psum[i + 1];
+        if (pe - ps > skew_param) continue;
+        uint64_t *W = minrec + (uint64_t)((uint32_t)words[i] >> kMinRecKeysLog2) * kMinRecWords;
+        const uint32_t local = (uint32_t)(i - (W[0] & kMinRecRankMask));
+        const uint64_t hdr = W[8];
+        for (uint64_t j = ps; j < pe; ++j) {
+            const uint64_t ent = entries[j];
+            const uint32_t fl = (uint32_t)(ent & 0xFFFFu), g = ((ent >> kEntryFlankBits) & 1) ? flank_revcomp(fl) : fl;
+            uint32_t word, bit;
+            if (minrec_filter_slot(hdr, local, g, word, bit)) atomicOr((unsigned long long *)&W[8 + word], 1ull << bit);
+        }
     }
 }
 // global partitioned Elias-Fano over psum (BlockedEF::build): block encode + overflow flag
@@ -455,8 +477,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
     hipLaunchKernelGGL(finish_records_kernel, dim3(grid_of(n_rec)), dim3(kB), 0, 0, d_minrec, n_rec, d_rrank, d_rcnt, d_psum, n_mm + 1, d_counter);
     BG_HIP(hipMemcpy(&h.n_minrec_overflow, d_counter, 8, hipMemcpyDeviceToHost));
     h.mm.n_keys = n_mm; h.mm.direct = 1; h.mm.levels.clear();
-    if (int rc = download(h.mm.blocks, d_minrec, n_rec * kMinRecWords)) return rc;
-    buf.release(d_minrec); buf.release(d_rcnt); buf.release(d_rrank);
+    buf.release(d_rcnt); buf.release(d_rrank); // d_minrec stays until its filters are filled from the entries
     phase("G3 minimizer records");
     if (timing) std::fprintf(stderr, "[mz gpu build] %llu of %llu minimizer records overflow to the global offsets\n", (unsigned long long)h.n_minrec_overflow, (unsigned long long)n_rec);
 
@@ -493,8 +514,11 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         uint64_t *d_packed = nullptr;
         BG_HIP(buf.alloc(&d_packed, n_words));
         hipLaunchKernelGGL(pos_entries_kernel, dim3(grid_of(n_words)), dim3(kB), 0, 0, d_keys, n_occ, P, h.pos.width, n_words, d_packed);
+        hipLaunchKernelGGL(record_filters_kernel, dim3(grid_of(n_mm)), dim3(kB), 0, 0, d_minrec, d_mm, n_mm, d_psum, d_packed, skew_param);
         if (int rc = download(h.pos.w, d_packed, n_words)) return rc;
         buf.release(d_packed);
+        if (int rc = download(h.mm.blocks, d_minrec, n_rec * kMinRecWords)) return rc;
+        buf.release(d_minrec);
     }
     phase("G3 offsets + pos entries");
 

@@ -399,6 +399,48 @@ MZ_HD bool direct_lookup(const uint64_t *blocks, uint64_t key, uint64_t &idx, ui
     if (local) *local = r;
     return member;
 }
+// flank16 of an entry emitted on the reverse strand, brought into the orientation of the canonical word g*: the 8 bases
+// reversed and complemented
+MZ_HD uint32_t flank_revcomp(uint32_t f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t x = __brev(f) >> 16;                    // bits reversed ...
+    x = ((x >> 1) & 0x5555u) | ((x & 0x5555u) << 1); // ... and swapped back inside each base
+#else
+    uint32_t x = f & 0xFFFFu;
+    x = ((x >> 8) & 0x00FFu) | ((x & 0x00FFu) << 8);
+    x = ((x >> 4) & 0x0F0Fu) | ((x & 0x0F0Fu) << 4);
+    x = ((x >> 2) & 0x3333u) | ((x & 0x3333u) << 2); // 2-bit groups reversed
+#endif
+    return x ^ 0xFFFFu;
+}
+// ---- negative filter in the slack of a record's offset block --------------------------------------------
+// The words of the partitioned-EF block between the end of its unary part and its bit planes are unused (typically 3-4 of
+// the 7: ~45 members, span ~130).  They hold a one-probe Bloom filter over (member index, inner flank) of every entry of
+// the record's LIGHT buckets; inner flank = the 2 bases left and the 2 right of the minimizer occurrence in the
+// orientation of the canonical k-mer (bits 4..11 of flank16).  A query whose k-mer covers those 4 bases and whose pattern
+// is absent cannot match any entry of its bucket: a foreign k-mer that merely shares a member minimizer (97 % of random
+// negatives at S-human) then stops after the record instead of fetching and scanning a bucket.  The decoder never looks
+// past the 64th one of the unary part, so the filter words are invisible to it.  Header bits 48..50 = number of filter
+// words, 51..53 = index of the first one.
+constexpr uint32_t kFilterFlankBases = 2;
+MZ_HD uint64_t minrec_filter_header(uint64_t bef_hdr, uint64_t span) {
+    const uint32_t l = (uint32_t)((bef_hdr >> 40) & 63);
+    const uint32_t unary_words = (uint32_t)(((span >> l) + kBefSpan + 1 + 63) >> 6);
+    const uint32_t first = 1 + unary_words, last = 7 - l; // words first..last are free
+    const uint32_t nf = last >= first ? last - first + 1 : 0;
+    return nf ? (((uint64_t)nf << 48) | ((uint64_t)first << 51)) : 0;
+}
+// filter slot of (member index inside the record, flank16 in the orientation of g*) as (word inside the block, bit);
+// returns false when the record has no filter
+MZ_HD bool minrec_filter_slot(uint64_t bef_hdr, uint32_t local, uint32_t flank16_g, uint32_t &word, uint32_t &bit) {
+    const uint32_t nf = (uint32_t)(bef_hdr >> 48) & 7u, first = (uint32_t)(bef_hdr >> 51) & 7u;
+    const uint32_t x = ((local << 8) | ((flank16_g >> 4) & 0xFFu)) * 0x9E3779B1u;
+    const uint32_t slot = ((x >> 16) * (nf * 64u)) >> 16;
+    word = first + (slot >> 6);
+    bit = slot & 63u;
+    return nf != 0 && (bef_hdr >> 63) == 0;
+}
+
 // member test + bucket id + bucket range from one record; `global` is the fallback for overflowed records
 MZ_HD bool minrec_lookup(const uint64_t *blocks, const BefView &global, uint64_t key, uint64_t &h, uint64_t &ps, uint64_t &pe) {
     uint32_t local;

@@ -120,12 +120,6 @@ __device__ __forceinline__ uint32_t query_flank(uint64_t g, uint32_t off, uint32
     const uint32_t qr = (uint32_t)(g >> (2 * (off + w))) & 0xFFu;
     return ql | (qr << 8);
 }
-// flank16 of an entry emitted on the reverse strand, brought into the orientation of g*: the 8 bases reversed and complemented
-__device__ __forceinline__ uint32_t flank_revcomp(uint32_t f) {
-    uint32_t x = __brev(f) >> 16;
-    x = ((x >> 1) & 0x5555u) | ((x & 0x5555u) << 1);
-    return x ^ 0xFFFFu;
-}
 
 // boundary half of a sequence+boundary record, fetched as four 16-byte loads (records are 128-byte aligned)
 struct SeqBoundary {
@@ -338,6 +332,15 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 const bool member = minrec_probe(w0[q], wv[qq], key[q], local[q]);
                 uint64_t ps = 0, pe = 0;
                 const bool ok = bef_decode_pair(L[qq], local[q] < kBefSpan ? local[q] : 0u, nullptr, ps, pe) && local[q] < kBefSpan;
+                // negative filter in the slack of the offset block: the query's inner flank must be among the entries of its bucket
+                const uint32_t qi = S.qinfo[i], off_a = (qi >> kQOffShift) & kQOffMask;
+                uint32_t fword, fbit;
+                const bool filtered = minrec_filter_slot(L[qq][0], local[q], qi, fword, fbit) && off_a >= kFilterFlankBases &&
+                                      k - w - off_a >= kFilterFlankBases; // the k-mer spans the inner flanks
+                uint32_t fx = 0;
+#pragma unroll
+                for (uint32_t j = 2; j < 8; ++j) fx |= fword == j ? (uint32_t)(L[qq][j] >> fbit) : 0u; // masked OR: no dynamic register index
+                const bool absent = filtered && !(fx & 1u);
                 bool heavy = false;
                 if (act) {
                     if (!member) {
@@ -346,7 +349,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                         const uint64_t cnt = pe - ps;
                         heavy = cnt > ix.skew_param;                        // sshash.rs:486-490
                         S.slot[i] = ps;
-                        S.n[i] = heavy ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
+                        S.n[i] = heavy ? kNSkew : absent ? kNMiss : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
                     } else {
                         slow |= 1u << q;
                     }

@@ -295,6 +295,25 @@ int Mphf::build(const uint64_t *keys_in, uint64_t n, double gamma, int n_threads
     return MZ_OK;
 }
 
+// negative filters of the minimizer records (mz_common.hpp): one bit per entry of every light bucket
+void Mphf::fill_filters(const uint64_t *keys, uint64_t n, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads) {
+    uint64_t *B = blocks.data();
+    parallel_for(n_threads, n, [=](int, uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) { // bucket id of keys[i] is i (monotone)
+            const uint64_t ps = psum[i], pe = psum[i + 1];
+            if (pe - ps > skew_param) continue; // heavy: answered by the skew index, never scanned
+            uint64_t *W = B + (uint64_t)((uint32_t)keys[i] >> kMinRecKeysLog2) * kMinRecWords;
+            const uint32_t local = (uint32_t)(i - (W[0] & kMinRecRankMask));
+            for (uint64_t j = ps; j < pe; ++j) {
+                const uint64_t ent = entries[j];
+                const uint32_t fl = (uint32_t)(ent & 0xFFFFu), g = ((ent >> kEntryFlankBits) & 1) ? flank_revcomp(fl) : fl;
+                uint32_t word, bit;
+                if (minrec_filter_slot(W[8], local, g, word, bit)) __atomic_fetch_or(&W[8 + word], 1ull << bit, __ATOMIC_RELAXED);
+            }
+        }
+    });
+}
+
 int Mphf::build_direct(const uint64_t *keys, uint64_t n, uint32_t key_bits, int n_threads) {
     if (key_bits > 32) {
         set_error("direct MPHF: key universe of 2^%u too large", key_bits);
@@ -341,6 +360,7 @@ uint64_t Mphf::fill_bucket_offsets(const uint64_t *psum, uint64_t n_psum, int n_
             uint64_t rank0 = W[0] & kMinRecRankMask;
             bool ok = c <= kBefSpan && rank0 + c < n_psum && bef_encode_block(psum + rank0, c, W + 8);
             if (!ok) { W[8] = 1ull << 63; OV[t]++; }
+            else W[8] |= minrec_filter_header(W[8], psum[rank0 + c] - psum[rank0]);
         }
     });
     uint64_t tot = 0;
@@ -809,7 +829,10 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     // 7. finish (sshash.rs:310-329): Elias-Fano the prefix sums, bit-pack the positions
     rc = buckets.build(psum.data(), n_mm + 1, nt);
     if (rc != MZ_OK) return rc;
-    if (mm.direct) n_minrec_overflow = mm.fill_bucket_offsets(psum.data(), n_mm + 1, nt);
+    if (mm.direct) {
+        n_minrec_overflow = mm.fill_bucket_offsets(psum.data(), n_mm + 1, nt);
+        mm.fill_filters(mm_set.data(), n_mm, psum.data(), posv.data(), skew_param, nt);
+    }
     pos.assign(posv.data(), n_occ, max_pos, nt);
     phase("EF + minrec + pack");
     build_seconds = now_s() - t0;
@@ -847,7 +870,7 @@ uint64_t SSHashHost::num_bits() const {
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '7'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '8'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>

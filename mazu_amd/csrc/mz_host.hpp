@@ -61,6 +61,7 @@ struct Mphf {
     int build_direct(const uint64_t *keys, uint64_t n, uint32_t key_bits, int n_threads);
     // direct mode: encode the bucket starts of every record's members into its second half; returns #records left to the global EF
     uint64_t fill_bucket_offsets(const uint64_t *psum, uint64_t n_psum, int n_threads);
+    void fill_filters(const uint64_t *keys, uint64_t n, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads);
     MphfView view() const { return MphfView{blocks.data(), levels.data(), (uint32_t)levels.size(), direct, n_keys}; }
     bool try_hash(uint64_t key, uint64_t &idx) const { return mphf_lookup(view(), key, idx); }
     uint64_t num_bits() const { return blocks.size() * 64 + levels.size() * sizeof(MphfLevel) * 8; }
