@@ -29,7 +29,7 @@ import mazu_amd as M  # noqa: E402
 from mazu_amd import synth  # noqa: E402
 
 B_ALG = 208.0        # algorithmic bytes per k-mer query on the 50/50 mix (table in DESIGN.md)
-B_ALG_OWN = 139.0    # same accounting for this repository's layout
+B_ALG_OWN = 134.0    # same accounting for this repository's layout
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 DEFAULT_BATCH = {"s-tiny": 200_000, "s-yeast": 10_000_000, "s-txome": 50_000_000, "s-eighth": 50_000_000, "s-human": 125_000_000}
