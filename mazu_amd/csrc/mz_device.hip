@@ -177,9 +177,28 @@ __device__ __forceinline__ void wave_push(T *list, uint32_t *cnt, bool pred, uin
     unsigned leader = (unsigned)(__ffsll((long long)b) - 1);
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(cnt, (uint32_t)__popcll(b));
-    base = __shfl(base, (int)leader);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader); // leader is wave-uniform: a scalar read, not an LDS-crossbar shuffle
     if (pred) list[base + __popcll(b & ((1ull << lane) - 1))] = (T)idx;
 }
+
+// wave64 inclusive scans on the VALU (DPP row shifts + row broadcasts, the classic 7-step sequence) instead of six
+// dependent ds_bpermute round trips through the LDS crossbar.  Values are unsigned; identity 0 serves both add and max.
+template <bool kMax>
+__device__ __forceinline__ uint32_t wave_scan(uint32_t x) {
+    auto op = [](uint32_t a, uint32_t b) { return kMax ? (a > b ? a : b) : a + b; };
+#define MZ_DPP(src, ctrl, rmask, bmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(src), ctrl, rmask, bmask, false)
+    uint32_t v = op(x, MZ_DPP(x, 0x111, 0xf, 0xf)); // row_shr:1
+    v = op(v, MZ_DPP(x, 0x112, 0xf, 0xf));          // row_shr:2
+    v = op(v, MZ_DPP(x, 0x113, 0xf, 0xf));          // row_shr:3
+    v = op(v, MZ_DPP(v, 0x114, 0xf, 0xe));          // row_shr:4, banks 1..3
+    v = op(v, MZ_DPP(v, 0x118, 0xf, 0xc));          // row_shr:8, banks 2..3
+    v = op(v, MZ_DPP(v, 0x142, 0xa, 0xf));          // row_bcast:15 into rows 1 and 3
+    v = op(v, MZ_DPP(v, 0x143, 0xc, 0xf));          // row_bcast:31 into rows 2 and 3
+#undef MZ_DPP
+    return v;
+}
+// value of the previous lane (0 for lane 0)
+__device__ __forceinline__ uint32_t wave_prev(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); } // wave_shr:1
 
 struct MphfProbe { // one level: issue the loads first, evaluate later
     uint64_t word, h0, h1;
@@ -407,11 +426,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
             eo[q] = sum;
             sum += nq[q];
         }
-        uint32_t incl = sum;
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(incl, d);
-            if ((int)(t & 63) >= d) incl += o;
-        }
+        const uint32_t incl = wave_scan<false>(sum);
         if constexpr (SC::NT > 64) {
             if ((t & 63) == 63) S.wave_tot[t >> 6] = incl;
             SC::sync();
@@ -444,14 +459,9 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 own[a] = S.list_a[t * kEpt + a];
                 if (a) own[a] = own[a] > own[a - 1] ? own[a] : own[a - 1];
             }
-            uint32_t run = own[kEpt - 1]; // inclusive max-scan over lanes (item indices grow with the entry index)
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t o = __shfl_up(run, d);
-                if ((int)(t & 63) >= d && o > run) run = o;
-            }
-            uint32_t before = __shfl_up(run, 1);
-            if ((t & 63) == 0) before = 0;
-            uint32_t total = __shfl(run, 63);
+            const uint32_t run = wave_scan<true>(own[kEpt - 1]); // inclusive max-scan over lanes (item indices grow with the entry index)
+            uint32_t before = wave_prev(run);
+            uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)run, 63);
             if constexpr (SC::NT > 64) {
                 if ((t & 63) == 63) S.wave_tot[t >> 6] = run;
                 SC::sync();
