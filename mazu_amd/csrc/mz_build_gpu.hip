@@ -299,59 +299,40 @@ __global__ __launch_bounds__(kB) void skew_tuples_kernel(const uint64_t *__restr
     }
 }
 
-__global__ __launch_bounds__(kB) void bbhash_mark_kernel(const uint64_t *__restrict__ keys, uint64_t n, MphfLevel L, uint64_t *occ, uint64_t *col) {
+// ---- skew table (SkewTable::build of the host) ----
+__global__ __launch_bounds__(kB) void skew_home_kernel(const uint64_t *__restrict__ words, uint64_t n, uint64_t n_buckets, uint64_t *__restrict__ hb,
+                                                       uint64_t *__restrict__ idx) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
     for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
-        uint32_t blk, bit;
-        mphf_level_slot(keys[i], L.seed, L.n_blocks, blk, bit);
-        const uint64_t wi = (uint64_t)blk * kMphfDataWords + (bit >> 6), m = 1ull << (bit & 63);
-        const unsigned long long old = atomicOr((unsigned long long *)&occ[wi], m);
-        if (old & m) atomicOr((unsigned long long *)&col[wi], m);
+        uint64_t b;
+        uint32_t fp;
+        skew_home(words[i], n_buckets, b, fp);
+        hb[i] = b;
+        idx[i] = i;
     }
 }
-// occ &= ~col, write the interleaved block (data words + 9-bit sub-counts), per-block popcount
-__global__ __launch_bounds__(kB) void bbhash_blocks_kernel(uint64_t *occ, const uint64_t *__restrict__ col, uint64_t n_blocks, uint64_t *__restrict__ blocks,
-                                                           uint64_t *__restrict__ block_ones) {
+__global__ __launch_bounds__(kB) void skew_heads_kernel(const uint64_t *__restrict__ hb, uint64_t n, uint64_t *__restrict__ head) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
-    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n_blocks; i += stride) {
-        uint64_t sub = 0, c = 0;
-        for (uint32_t j = 0; j < kMphfDataWords; ++j) {
-            const uint64_t wv = occ[i * kMphfDataWords + j] & ~col[i * kMphfDataWords + j];
-            occ[i * kMphfDataWords + j] = wv;
-            blocks[i * 8 + 2 + j] = wv;
-            sub |= c << (9 * j);
-            c += popc64(wv);
-        }
-        blocks[i * 8 + 1] = sub;
-        blocks[i * 8 + 0] = 0;
-        block_ones[i] = c;
-    }
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < n; j += stride) head[j] = (j == 0 || hb[j] != hb[j - 1]) ? j : 0;
 }
-struct NotPlaced { // keys whose bit did not survive go to the next level
-    const uint64_t *occ;
-    MphfLevel L;
-    __host__ __device__ bool operator()(uint64_t key) const {
-        uint32_t blk, bit;
-        mphf_level_slot(key, L.seed, L.n_blocks, blk, bit);
-        return !((occ[(uint64_t)blk * kMphfDataWords + (bit >> 6)] >> (bit & 63)) & 1);
-    }
-};
-__global__ __launch_bounds__(kB) void set_block_ranks_kernel(uint64_t *blocks, const uint64_t *__restrict__ ranks, uint64_t n_blocks) {
+__global__ __launch_bounds__(kB) void skew_place_kernel(const uint64_t *__restrict__ hb, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ first,
+                                                        const uint64_t *__restrict__ words, const uint64_t *__restrict__ pos, uint64_t n, uint64_t n_buckets,
+                                                        uint64_t *__restrict__ table, uint8_t *__restrict__ ovflag) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
-    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n_blocks; i += stride) blocks[i * 8] = ranks[i];
-}
-__global__ __launch_bounds__(kB) void skew_pos_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pos, uint64_t n, MphfView m, uint32_t width,
-                                                      uint64_t *packed) {
-    uint64_t stride = (uint64_t)gridDim.x * kB;
-    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
-        uint64_t h = 0;
-        mphf_lookup(m, words[i], h);
-        const uint64_t b = h * width, wi = b >> 6, v = pos[i];
-        const uint32_t sh = (uint32_t)(b & 63);
-        atomicOr((unsigned long long *)&packed[wi], v << sh);
-        if (sh + width > 64) atomicOr((unsigned long long *)&packed[wi + 1], v >> (64 - sh));
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < n; j += stride) {
+        const uint64_t rank = j - first[j], i = idx[j];
+        uint64_t b;
+        uint32_t fp;
+        skew_home(words[i], n_buckets, b, fp);
+        if (rank < kSkewSlots) table[hb[j] * kSkewSlots + rank] = skew_slot(fp, pos[i]);
+        ovflag[j] = rank >= kSkewSlots;
     }
 }
+__global__ __launch_bounds__(kB) void gather_kernel(const uint64_t *__restrict__ src, const uint64_t *__restrict__ idx, uint64_t n, uint64_t *__restrict__ dst) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < n; j += stride) dst[j] = src[idx[j]];
+}
+
 __global__ __launch_bounds__(kB) void first_of_run_kernel(const uint64_t *__restrict__ words, uint64_t n, uint8_t *__restrict__ flag) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
     for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) flag[i] = i == 0 || words[i] != words[i - 1];
@@ -549,74 +530,40 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
             buf.release(d_first);
         }
         phase("G4 skew tuples + sort");
-        // BBHash levels over d_tw2[0..sn) (Mphf::build of the host, same seeds / sizes / gamma)
-        Mphf &m = h.skew;
-        m.n_keys = sn; m.direct = 0; m.levels.clear(); m.blocks.clear();
-        uint64_t *d_kcur = d_tw, *d_knext = nullptr; // d_tw is free again: reuse as the live key list
-        if (sn) BG_HIP(hipMemcpy(d_kcur, d_tw2, sn * 8, hipMemcpyDeviceToDevice));
-        BG_HIP(buf.alloc(&d_knext, sn));
-        uint64_t rem = sn, total_blocks = 0, lvl_seed = 0x9E3779B97F4A7C15ull;
-        std::vector<uint64_t *> lvl_blocks;
-        std::vector<uint64_t> lvl_nb;
-        uint64_t *d_ones_all = nullptr; // per-block popcounts of all levels, concatenated later
-        std::vector<uint64_t *> lvl_ones;
-        while (rem > 0) {
-            if (m.levels.size() >= kMphfMaxLevels) { set_error("MPHF: more than %u levels (duplicate keys?)", kMphfMaxLevels); return MZ_EINVAL; }
-            const uint64_t nb = (uint64_t)((1.7 * (double)rem) / kMphfBitsPerBlock) + 1;
-            lvl_seed = lvl_seed * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull;
-            MphfLevel L{total_blocks, lvl_seed, (uint32_t)nb, 0};
-            uint64_t *d_occ = nullptr, *d_col = nullptr, *d_blk = nullptr, *d_ones = nullptr;
-            BG_HIP(buf.alloc(&d_occ, nb * kMphfDataWords)); BG_HIP(buf.alloc(&d_col, nb * kMphfDataWords));
-            BG_HIP(buf.alloc(&d_blk, nb * 8)); BG_HIP(buf.alloc(&d_ones, nb));
-            BG_HIP(hipMemset(d_occ, 0, nb * kMphfDataWords * 8)); BG_HIP(hipMemset(d_col, 0, nb * kMphfDataWords * 8));
-            hipLaunchKernelGGL(bbhash_mark_kernel, dim3(grid_of(rem)), dim3(kB), 0, 0, d_kcur, rem, L, d_occ, d_col);
-            hipLaunchKernelGGL(bbhash_blocks_kernel, dim3(grid_of(nb)), dim3(kB), 0, 0, d_occ, d_col, nb, d_blk, d_ones);
-            ROCPRIM_RUN(buf, rocprim::select(tmp, tmp_bytes, d_kcur, d_knext, d_nsel, rem, NotPlaced{d_occ, L}));
-            uint64_t nr = 0;
-            BG_HIP(hipMemcpy(&nr, d_nsel, 8, hipMemcpyDeviceToHost));
-            buf.release(d_occ); buf.release(d_col);
-            lvl_blocks.push_back(d_blk); lvl_nb.push_back(nb); lvl_ones.push_back(d_ones);
-            m.levels.push_back(L);
-            total_blocks += nb;
-            std::swap(d_kcur, d_knext);
-            rem = nr;
-        }
-        (void)d_ones_all;
-        // absolute ranks over the concatenated levels
-        if (total_blocks) {
-            uint64_t *d_all = nullptr, *d_ones = nullptr, *d_ranks = nullptr;
-            BG_HIP(buf.alloc(&d_all, total_blocks * 8)); BG_HIP(buf.alloc(&d_ones, total_blocks)); BG_HIP(buf.alloc(&d_ranks, total_blocks));
-            uint64_t off = 0;
-            for (size_t l = 0; l < lvl_nb.size(); ++l) {
-                BG_HIP(hipMemcpy(d_all + off * 8, lvl_blocks[l], lvl_nb[l] * 64, hipMemcpyDeviceToDevice));
-                BG_HIP(hipMemcpy(d_ones + off, lvl_ones[l], lvl_nb[l] * 8, hipMemcpyDeviceToDevice));
-                buf.release(lvl_blocks[l]); buf.release(lvl_ones[l]);
-                off += lvl_nb[l];
+        // skew table over d_tw2[0..sn) (word order) / d_tp2 (SkewTable::build of the host)
+        SkewTable &st = h.skew;
+        st.n_keys = sn;
+        st.n_buckets = sn ? (sn + kSkewLoad - 1) / kSkewLoad : 0;
+        st.ovf_word.clear();
+        st.ovf_pos.clear();
+        const uint64_t n_slots = std::max<uint64_t>(st.n_buckets * kSkewSlots, 2);
+        if (sn) {
+            uint64_t *d_tab = nullptr, *d_hb = d_tw, *d_ix = d_tp, *d_hb2 = nullptr, *d_ix2 = nullptr, *d_first = nullptr;
+            uint8_t *d_ovflag = nullptr;
+            BG_HIP(buf.alloc(&d_tab, n_slots));
+            BG_HIP(buf.alloc(&d_hb2, sn)); BG_HIP(buf.alloc(&d_ix2, sn)); BG_HIP(buf.alloc(&d_first, sn)); BG_HIP(buf.alloc(&d_ovflag, sn));
+            BG_HIP(hipMemset(d_tab, 0xFF, n_slots * 8));
+            hipLaunchKernelGGL(skew_home_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_tw2, sn, st.n_buckets, d_hb, d_ix);
+            // stable sort by home bucket: the keys of a bucket stay in word order
+            ROCPRIM_RUN(buf, rocprim::radix_sort_pairs(tmp, tmp_bytes, d_hb, d_hb2, d_ix, d_ix2, sn, 0, bit_len(st.n_buckets)));
+            hipLaunchKernelGGL(skew_heads_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_hb2, sn, d_hb); // d_hb reused: head positions
+            ROCPRIM_RUN(buf, rocprim::inclusive_scan(tmp, tmp_bytes, d_hb, d_first, sn, rocprim::maximum<uint64_t>()));
+            hipLaunchKernelGGL(skew_place_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_hb2, d_ix2, d_first, d_tw2, d_tp2, sn, st.n_buckets, d_tab, d_ovflag);
+            ROCPRIM_RUN(buf, rocprim::select(tmp, tmp_bytes, d_ix2, d_ovflag, d_ix, d_nsel, sn)); // d_ix reused: overflowed key indices, in (bucket, word) order
+            uint64_t n_ovf = 0;
+            BG_HIP(hipMemcpy(&n_ovf, d_nsel, 8, hipMemcpyDeviceToHost));
+            if (n_ovf) {
+                hipLaunchKernelGGL(gather_kernel, dim3(grid_of(n_ovf)), dim3(kB), 0, 0, d_tw2, d_ix, n_ovf, d_hb2);
+                hipLaunchKernelGGL(gather_kernel, dim3(grid_of(n_ovf)), dim3(kB), 0, 0, d_tp2, d_ix, n_ovf, d_first);
+                if (int rc = download(st.ovf_word, d_hb2, n_ovf)) return rc;
+                if (int rc = download(st.ovf_pos, d_first, n_ovf)) return rc;
             }
-            ROCPRIM_RUN(buf, rocprim::exclusive_scan(tmp, tmp_bytes, d_ones, d_ranks, (uint64_t)0, total_blocks, rocprim::plus<uint64_t>()));
-            hipLaunchKernelGGL(set_block_ranks_kernel, dim3(grid_of(total_blocks)), dim3(kB), 0, 0, d_all, d_ranks, total_blocks);
-            if (int rc = download(m.blocks, d_all, total_blocks * 8)) return rc;
-            // skew_pos[h(word)] = pos, packed at bit_len(total_len)
-            MphfLevel *d_levels = nullptr;
-            BG_HIP(buf.alloc(&d_levels, m.levels.size()));
-            BG_HIP(hipMemcpy(d_levels, m.levels.data(), m.levels.size() * sizeof(MphfLevel), hipMemcpyHostToDevice));
-            MphfView mv{d_all, d_levels, (uint32_t)m.levels.size(), 0, sn};
-            h.skew_pos.n = sn;
-            h.skew_pos.width = bit_len(us.total_len);
-            const uint64_t n_words = (sn * h.skew_pos.width + 63) / 64 + 2;
-            uint64_t *d_sp = nullptr;
-            BG_HIP(buf.alloc(&d_sp, n_words));
-            BG_HIP(hipMemset(d_sp, 0, n_words * 8));
-            hipLaunchKernelGGL(skew_pos_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_tw2, d_tp2, sn, mv, h.skew_pos.width, d_sp);
-            if (int rc = download(h.skew_pos.w, d_sp, n_words)) return rc;
+            if (int rc = download(st.buckets, d_tab, n_slots)) return rc;
         } else {
-            m.blocks.assign(8, 0);
-            h.skew_pos.n = 0;
-            h.skew_pos.width = bit_len(us.total_len);
-            h.skew_pos.w.assign(2, 0);
+            st.buckets.assign(n_slots, kSkewEmpty);
         }
         h.has_skew = true;
-        phase("G4 skew mphf + pos");
+        phase("G4 skew table");
     }
     BG_HIP(hipDeviceSynchronize());
     BG_HIP(hipGetLastError());

@@ -195,7 +195,7 @@ uint32_t mz_sshash_w(const mz_sshash *ix) { return ix->host.w; }
 uint64_t mz_sshash_skew_param(const mz_sshash *ix) { return ix->host.skew_param; }
 uint64_t mz_sshash_n_minimizers(const mz_sshash *ix) { return ix->host.n_minimizers; }
 uint64_t mz_sshash_n_minimizer_occs(const mz_sshash *ix) { return ix->host.pos.n; }
-uint64_t mz_sshash_n_kmers_in_skew_index(const mz_sshash *ix) { return ix->host.has_skew ? ix->host.skew_pos.n : 0; }
+uint64_t mz_sshash_n_kmers_in_skew_index(const mz_sshash *ix) { return ix->host.has_skew ? ix->host.skew.n_keys : 0; }
 uint64_t mz_sshash_num_bits(const mz_sshash *ix) { return ix->host.num_bits(); }
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix) { return ix->dev ? ix->dev->bytes : 0; } /* per replica */
 

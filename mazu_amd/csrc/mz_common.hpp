@@ -337,6 +337,27 @@ MZ_HD void bef_get_pair(const BefView &e, uint64_t i, uint64_t &v0, uint64_t &v1
     bef_block_pair(e.blocks + (i >> kBefShift) * 8, (uint32_t)(i & (kBefSpan - 1)), e.ovf, v0, v1);
 }
 
+// ---- skew index (reference SkewIndex: boomphf over the canonical k-mers of the heavy buckets + a position per slot,
+// sshash.rs:53-66) as ONE gather: a hash table of 128-byte buckets, 16 slots of (28-bit fingerprint << 36 | global k-mer
+// position), empty = all ones.  A k-mer lives in its home bucket; the keys of a bucket are kept in increasing word order
+// and the few beyond the 16th (load is 8 per bucket: 0.4 % of the buckets) go to a small list sorted by (bucket, word).
+// The k-mer found through a fingerprint is verified against the sequence like every other candidate.
+constexpr uint32_t kSkewSlots = 16, kSkewFpBits = 28, kSkewPosBits = 36, kSkewLoad = 8;
+constexpr uint64_t kSkewSeed = 0x6d617a755f736b77ull, kSkewEmpty = ~0ull;
+struct SkewView {
+    const uint64_t *buckets;   // n_buckets * 16 slots
+    const uint64_t *ovf_word;  // overflowed keys, sorted by (home bucket, word)
+    const uint64_t *ovf_pos;
+    uint64_t n_buckets, n_ovf, n_keys;
+};
+MZ_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((__uint128_t)a * b) >> 64);
+#endif
+}
+
 struct IndexView {
     uint32_t k, w;
     uint64_t seed;
@@ -350,10 +371,7 @@ struct IndexView {
     const uint64_t *pos;       // packed entries: (minimizer position << 17) | (strand class << 16) | flank16
     uint32_t pos_width;
     uint32_t has_skew;
-    MphfView skew;             // canonical k-mer -> slot in skew_pos
-    const uint64_t *skew_pos;  // packed k-mer positions
-    uint32_t skew_pos_width;
-    uint32_t pad;
+    SkewView skew;             // canonical k-mer of a heavy bucket -> global k-mer position
     const uint64_t *starts;    // plain unitig starts (n_unitigs+1); used by validate_self only
 };
 
@@ -630,14 +648,45 @@ MZ_HD mz_k2upos make_hit(const UnitigSpan &s, uint64_t km_pos, uint32_t mt) {
 }
 
 // sshash.rs:415-433 + SkewIndex::lookup :59-66
+// home bucket and fingerprint of a canonical k-mer word
+MZ_HD void skew_home(uint64_t word, uint64_t n_buckets, uint64_t &bucket, uint32_t &fp) {
+    const uint64_t h = mum(word ^ kSkewSeed, kP1);
+    bucket = mulhi64(h ^ (h >> 32), n_buckets);
+    fp = (uint32_t)h & ((1u << kSkewFpBits) - 1);
+}
+MZ_HD uint64_t skew_slot(uint32_t fp, uint64_t pos) { return ((uint64_t)fp << kSkewPosBits) | pos; }
+// exact lookup (every slot with the k-mer's fingerprint is verified, then the overflow list): sshash.rs:415-433 + :59-66
 MZ_HD mz_k2upos skew_lookup(const IndexView &ix, uint64_t fw, uint64_t rc) {
-    if (!ix.has_skew) return make_none();
-    uint64_t word = fw < rc ? fw : rc, h;
-    if (!mphf_lookup(ix.skew, word, h)) return make_none();
-    uint64_t p = read_packed(ix.skew_pos, h, ix.skew_pos_width);
-    uint32_t mt = word_equivalency(fw, rc, read_kmer_i(ix.seqbv, p, ix.k));
-    if (mt == MZ_NO_MATCH) return make_none();
-    return make_hit(locate_unitig_i(ix.seqbv, p), p, mt);
+    if (!ix.has_skew || ix.skew.n_buckets == 0) return make_none();
+    const uint64_t word = fw < rc ? fw : rc;
+    uint64_t b;
+    uint32_t fp;
+    skew_home(word, ix.skew.n_buckets, b, fp);
+    const uint64_t *B = ix.skew.buckets + b * kSkewSlots;
+    uint32_t used = 0;
+    for (; used < kSkewSlots; ++used) {
+        const uint64_t e = B[used];
+        if (e == kSkewEmpty) break;
+        if ((uint32_t)(e >> kSkewPosBits) != fp) continue;
+        const uint64_t p = e & ((1ull << kSkewPosBits) - 1);
+        const uint32_t mt = word_equivalency(fw, rc, read_kmer_i(ix.seqbv, p, ix.k));
+        if (mt != MZ_NO_MATCH) return make_hit(locate_unitig_i(ix.seqbv, p), p, mt);
+    }
+    if (used < kSkewSlots) return make_none();
+    uint64_t lo = 0, hi = ix.skew.n_ovf; // first overflow key >= (b, word)
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1, mw = ix.skew.ovf_word[mid];
+        uint64_t mb;
+        uint32_t mf;
+        skew_home(mw, ix.skew.n_buckets, mb, mf);
+        if (mb < b || (mb == b && mw < word)) lo = mid + 1; else hi = mid;
+    }
+    if (lo < ix.skew.n_ovf && ix.skew.ovf_word[lo] == word) {
+        const uint64_t p = ix.skew.ovf_pos[lo];
+        const uint32_t mt = word_equivalency(fw, rc, read_kmer_i(ix.seqbv, p, ix.k));
+        if (mt != MZ_NO_MATCH) return make_hit(locate_unitig_i(ix.seqbv, p), p, mt);
+    }
+    return make_none();
 }
 
 // sshash.rs:478-554 once the canonical minimizer is known

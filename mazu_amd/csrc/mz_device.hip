@@ -515,25 +515,37 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     }
     SC::sync();
     if constexpr (kStopAfter == 3) return;
-    // ---- S4: heavy buckets go through the skew index (sshash.rs:415-433)
+    // ---- S4: heavy buckets go through the skew index (sshash.rs:415-433): ONE gather of the k-mer's 128-byte home bucket;
+    //          the slot with its fingerprint gives the candidate position for S5.  More than one such slot, or none in a
+    //          full bucket (its keys may have overflowed), only raises the item's flag: S5 then falls back to the exact walk.
     if (S.cnt_skew != 0) { // uniform
         const uint32_t ns = S.cnt_skew;
         SC::sync();
-        if (ix.has_skew) {
+        if (ix.has_skew && ix.skew.n_buckets != 0) {
             for (uint32_t j = t; j < ns; j += SC::NT) {
-                uint32_t i = S.list_b[j];
-                uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                S.slot[i] = fw < rc ? fw : rc;
-                S.list_a[j] = (uint16_t)i;
-                S.eoff[j] = i; // eoff is free now: remember the heavy items across the level loop
-            }
-            if (t == 0) { S.cnt_a = ns; S.cnt_b = 0; }
-            SC::sync();
-            tile_mphf<SC>(S, ix.skew, false);
-            for (uint32_t j = t; j < ns; j += SC::NT) {
-                uint32_t i = S.eoff[j];
-                if (S.n[i] == kNMiss) continue;
-                S.best[i] = read_packed(ix.skew_pos, S.slot[i], ix.skew_pos_width); // the one candidate of a heavy item
+                const uint32_t i = S.list_b[j];
+                const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
+                uint64_t hb;
+                uint32_t fp;
+                skew_home(fw < rc ? fw : rc, ix.skew.n_buckets, hb, fp);
+                const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(ix.skew.buckets + hb * kSkewSlots);
+                ulonglong2 sl[kSkewSlots / 2];
+#pragma unroll
+                for (uint32_t q = 0; q < kSkewSlots / 2; ++q) sl[q] = v[q];
+                uint64_t cand = kBestNone;
+                uint32_t n_match = 0;
+                bool full = true;
+#pragma unroll
+                for (int q = (int)kSkewSlots - 1; q >= 0; --q) { // downwards: `cand` ends as the FIRST matching slot
+                    const uint64_t e = (q & 1) ? sl[q >> 1].y : sl[q >> 1].x;
+                    if (e == kSkewEmpty) full = false;
+                    else if ((uint32_t)(e >> kSkewPosBits) == fp) { cand = e & ((1ull << kSkewPosBits) - 1); ++n_match; }
+                }
+                if (n_match != 1 && (n_match > 1 || full)) {
+                    S.qinfo[i] |= kQMulti;
+                    if (n_match == 0) cand = 0; // any valid position: its verification fails and the flag sends the item to the exact walk
+                }
+                S.best[i] = cand;
             }
         }
         SC::sync();
@@ -1061,8 +1073,10 @@ int device_upload(const SSHashHost &h, int device, DeviceIndex **out) {
     if ((rc = upload(d, h.buckets.ovf.data(), h.buckets.ovf.size(), &v.buckets.ovf)) != MZ_OK) return fail(rc);
     if ((rc = upload(d, h.pos.w.data(), h.pos.w.size(), &v.pos)) != MZ_OK) return fail(rc);
     if (h.has_skew) {
-        if ((rc = upload_mphf(d, h.skew, &v.skew)) != MZ_OK) return fail(rc);
-        if ((rc = upload(d, h.skew_pos.w.data(), h.skew_pos.w.size(), &v.skew_pos)) != MZ_OK) return fail(rc);
+        v.skew = h.skew.view();
+        if ((rc = upload(d, h.skew.buckets.data(), h.skew.buckets.size(), &v.skew.buckets)) != MZ_OK) return fail(rc);
+        if ((rc = upload(d, h.skew.ovf_word.data(), h.skew.ovf_word.size(), &v.skew.ovf_word)) != MZ_OK) return fail(rc);
+        if ((rc = upload(d, h.skew.ovf_pos.data(), h.skew.ovf_pos.size(), &v.skew.ovf_pos)) != MZ_OK) return fail(rc);
     }
     d->view = v;
     *out = d;

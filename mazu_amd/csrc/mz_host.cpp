@@ -656,6 +656,41 @@ static void scan_unitig(const uint64_t *useq, uint64_t s, uint64_t e, uint32_t k
     }
 }
 
+void SkewTable::build(const uint64_t *words, const uint64_t *pos, uint64_t n, int n_threads) {
+    n_keys = n;
+    n_buckets = n ? (n + kSkewLoad - 1) / kSkewLoad : 0;
+    buckets.assign(std::max<uint64_t>(n_buckets * kSkewSlots, 2), kSkewEmpty);
+    ovf_word.clear();
+    ovf_pos.clear();
+    if (n == 0) return;
+    // (home bucket, index) pairs in increasing order: inside a bucket the keys keep their word order
+    std::vector<Occ> by(n);
+    {
+        Occ *BY = by.data();
+        const uint64_t nb = n_buckets;
+        parallel_for(n_threads, n, [=](int, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+                uint64_t hb;
+                uint32_t fp;
+                skew_home(words[i], nb, hb, fp);
+                BY[i] = Occ{hb, i};
+            }
+        });
+    }
+    sort_occs(by, bit_len(n_buckets), n_threads);
+    uint64_t *B = buckets.data();
+    uint64_t run_start = 0;
+    for (uint64_t j = 0; j < n; ++j) { // serial: one pass, ranks inside the runs of equal buckets
+        if (j && by[j].word != by[j - 1].word) run_start = j;
+        const uint64_t rank = j - run_start, i = by[j].pos;
+        uint64_t hb;
+        uint32_t fp;
+        skew_home(words[i], n_buckets, hb, fp);
+        if (rank < kSkewSlots) B[hb * kSkewSlots + rank] = skew_slot(fp, pos[i]);
+        else { ovf_word.push_back(words[i]); ovf_pos.push_back(pos[i]); }
+    }
+}
+
 int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads) {
     double t0 = now_s();
     const bool timing = std::getenv("MZ_BUILD_TIMING") != nullptr;
@@ -806,23 +841,10 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
         sort_occs(tup, 2 * k, nt);
         tup.erase(std::unique(tup.begin(), tup.end(), [](const Occ &a, const Occ &b) { return a.word == b.word; }), tup.end());
         uint64_t sn = tup.size();
-        std::vector<uint64_t> km_set(sn), spos(sn, 0);
-        for (uint64_t i = 0; i < sn; ++i) km_set[i] = tup[i].word;
-        rc = skew.build(km_set.data(), sn, 1.7, nt);
-        if (rc != MZ_OK) return rc;
-        {
-            MphfView sv = skew.view();
-            uint64_t *SP = spos.data();
-            const Occ *T = tup.data();
-            parallel_for(nt, sn, [=](int, uint64_t b, uint64_t e) {
-                for (uint64_t i = b; i < e; ++i) {
-                    uint64_t h = 0;
-                    mphf_lookup(sv, T[i].word, h);
-                    SP[h] = T[i].pos;
-                }
-            });
-        }
-        skew_pos.assign(spos.data(), sn, us.total_len, nt);
+        std::vector<uint64_t> km_set(sn), spos(sn);
+        for (uint64_t i = 0; i < sn; ++i) { km_set[i] = tup[i].word; spos[i] = tup[i].pos; }
+        std::vector<Occ>().swap(tup);
+        skew.build(km_set.data(), spos.data(), sn, nt);
         has_skew = true;
     }
     phase("skew index");
@@ -855,8 +877,6 @@ IndexView SSHashHost::view() const {
     v.has_skew = has_skew ? 1 : 0;
     if (has_skew) {
         v.skew = skew.view();
-        v.skew_pos = skew_pos.w.data();
-        v.skew_pos_width = skew_pos.width;
     }
     v.starts = us.starts.data();
     return v;
@@ -865,12 +885,12 @@ IndexView SSHashHost::view() const {
 // sshash.rs:341-358 (the MPHF term is the exact size of ours, not a bincode estimate)
 uint64_t SSHashHost::num_bits() const {
     uint64_t b = 64 + us.num_bits() + buckets.num_bits() + pos.num_bits() + mm.num_bits();
-    if (has_skew) b += skew.num_bits() + skew_pos.num_bits();
+    if (has_skew) b += skew.num_bits();
     return b;
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '8'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '9'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>
@@ -907,7 +927,7 @@ int SSHashHost::save(const std::string &path) const {
     put(f, hs);
     putv(f, us.useq); putv(f, us.starts); putv(f, us.bv_blocks); put_ef(f, us.accum_lens);
     put_mphf(f, mm); put(f, buckets.n); put(f, buckets.n_overflow); putv(f, buckets.blocks); putv(f, buckets.ovf); put_pv(f, pos);
-    if (has_skew) { put_mphf(f, skew); put_pv(f, skew_pos); }
+    if (has_skew) { put(f, skew.n_buckets); put(f, skew.n_keys); putv(f, skew.buckets); putv(f, skew.ovf_word); putv(f, skew.ovf_pos); }
     return f ? MZ_OK : (set_error("short write to %s", path.c_str()), MZ_EIO);
 }
 
@@ -923,7 +943,8 @@ int SSHashHost::load(const std::string &path) {
               get(f, n_minimizers) && get(f, hs) && getv(f, us.useq) && getv(f, us.starts) && getv(f, us.bv_blocks) &&
               get_ef(f, us.accum_lens) && get_mphf(f, mm) && get(f, buckets.n) && get(f, buckets.n_overflow) && getv(f, buckets.blocks) && getv(f, buckets.ovf) && get_pv(f, pos) && pos.width == kPosEntryBits;
     has_skew = hs != 0;
-    if (ok && has_skew) ok = get_mphf(f, skew) && get_pv(f, skew_pos);
+    if (ok && has_skew) ok = get(f, skew.n_buckets) && get(f, skew.n_keys) && getv(f, skew.buckets) && getv(f, skew.ovf_word) && getv(f, skew.ovf_pos) &&
+                             skew.buckets.size() == std::max<uint64_t>(skew.n_buckets * kSkewSlots, 2) && skew.ovf_word.size() == skew.ovf_pos.size();
     if (ok) us.build_seqbv();
     if (!ok) {
         set_error("%s: truncated", path.c_str());

@@ -91,6 +91,16 @@ private:
 };
 
 // SSHash (reference src/kphf/sshash.rs:39-57)
+// Hash table of the skew index (layout: SkewView in mz_common.hpp).  build() takes the k-mer words in increasing order
+// with their positions; the result depends only on that set (the GPU builder produces the same arrays).
+struct SkewTable {
+    std::vector<uint64_t> buckets, ovf_word, ovf_pos;
+    uint64_t n_buckets = 0, n_keys = 0;
+    void build(const uint64_t *words, const uint64_t *pos, uint64_t n, int n_threads);
+    SkewView view() const { return SkewView{buckets.data(), ovf_word.data(), ovf_pos.data(), n_buckets, (uint64_t)ovf_word.size(), n_keys}; }
+    uint64_t num_bits() const { return 64 * (uint64_t)(buckets.size() + ovf_word.size() + ovf_pos.size()); }
+};
+
 struct SSHashHost {
     UnitigSet us;
     uint32_t w = 0;
@@ -100,8 +110,7 @@ struct SSHashHost {
     BlockedEF buckets; // occs_prefix_sum
     PackedVec pos;    // pos
     bool has_skew = false;
-    Mphf skew;        // skew_index.mphf
-    PackedVec skew_pos;
+    SkewTable skew;   // skew index: canonical k-mer of a heavy bucket -> global k-mer position (SkewView in mz_common.hpp)
     uint64_t n_minimizers = 0, n_minrec_overflow = 0;
     double build_seconds = 0;
 

@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
         std::printf("{\"n_kmers\": %llu, \"n_fail\": %llu, \"n_minimizers\": %llu, \"n_occs\": %llu, \"n_skew\": %llu, \"mphf_levels\": %zu, "
                     "\"ef_overflow_blocks\": %llu, \"direct\": %u, \"minrec_overflow\": %llu, \"num_bits\": %llu, \"build_s\": %.3f}\n",
                     (unsigned long long)n, (unsigned long long)fails, (unsigned long long)h.n_minimizers, (unsigned long long)h.pos.n,
-                    (unsigned long long)(h.has_skew ? h.skew_pos.n : 0), h.mm.levels.size(), (unsigned long long)h.buckets.n_overflow, h.mm.direct, (unsigned long long)h.n_minrec_overflow,
+                    (unsigned long long)(h.has_skew ? h.skew.n_keys : 0), h.mm.levels.size(), (unsigned long long)h.buckets.n_overflow, h.mm.direct, (unsigned long long)h.n_minrec_overflow,
                     (unsigned long long)h.num_bits(), h.build_seconds);
         return fails ? 3 : 0;
     }
