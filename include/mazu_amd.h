@@ -116,7 +116,7 @@ const uint64_t *mz_unitig_set_useq_words(const mz_unitig_set *us);
 int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed,
                               int n_threads, mz_sshash **out);
 /* same construction with the heavy steps on the GPU `device` (minimizer scan with the window staged in LDS, radix sort,
- * minimizer records, Elias-Fano, packed entries, skew MPHF): bit-identical arrays to the host builder.  Configurations it
+ * minimizer records, Elias-Fano, entries, skew table): bit-identical arrays to the host builder.  Configurations it
  * does not cover (w > 16, or an occurrence not fitting one 64-bit sort key) are built on the host transparently. */
 int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int device,
                                      mz_sshash **out);

@@ -7,8 +7,9 @@
 //   G2  radix sort + unique (rocPRIM device primitives), run-length -> minimizer set, bucket sizes,
 //       exclusive scan -> bucket starts
 //   G3  minimizer records (membership bitmap, ranks, per-record Elias-Fano halves), global partitioned
-//       Elias-Fano, packed `pos` entries with strand class and flank fingerprint
-//   G4  skew index: k-mers around heavy minimizers, sort/unique, BBHash levels built with atomics
+//       Elias-Fano, 64-bit `pos` entries with strand class and flank fingerprint, negative filters of the records
+//   G4  skew index: k-mers around heavy minimizers, sort/unique, hash table of 128-byte buckets (stable sort by home
+//       bucket, rank inside the bucket, overflow list)
 // Restrictions (otherwise the caller falls back to the host builder): direct-address minimizer records
 // (2w <= 32) and 2w + bit_len(total_len) + 1 <= 64 so that an occurrence fits one 64-bit sort key.
 #include <hip/hip_runtime.h>

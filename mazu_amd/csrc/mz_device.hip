@@ -79,15 +79,15 @@ __global__ __launch_bounds__(kBlock) void k2u_batch_kernel(IndexView ix, const u
 // sshash.rs:471-554 is cut into stages separated by barriers, and between stages the work is
 // re-compacted with wavefront ballots so that every vector memory instruction is issued by
 // (nearly) full waves, with several independent gathers in flight per lane:
-//   S0  canonical encode + minimizer (ALU only)                      dense over queries
-//   S1  MPHF probe, one level (pair) per round; unresolved keys are ballot-compacted into an
-//       LDS list for the next round (geometric shrink)               dense over pending keys
-//   S2  Elias-Fano get(h), get(h+1) -> bucket range                  dense over queries
-//   S3  bucket entries flattened by an LDS prefix sum: one (query, entry) item per lane
-//       iteration: packed (pos, strand class) -> the one candidate k-mer of that class ->
-//       verify; the first verified entry in bucket order is kept with an LDS atomicMin
-//   S4  heavy buckets: skew MPHF (same level loop) -> packed pos -> verify
-//   S5  unitig locate + boundary check of the winner (exact rescan if it straddles two unitigs),
+//   S0  canonical encode + minimizer + the flank pattern an entry must show (ALU only)        dense over queries
+//   S1  minimizer record: {header, bitmap word} probe + bucket-offset block + negative filter, all loads of the
+//       128-byte line in one batch (BBHash path: one level set per round, unresolved keys ballot-compacted into
+//       an LDS list; then the partitioned Elias-Fano block)                                  dense over queries
+//   S3  bucket entries of the tile flattened by an LDS prefix sum; owners from a max-scan over bucket-head marks;
+//       entry -> flank filter; the first survivor in bucket order is the item's candidate (LDS atomicMin)
+//   S4  heavy buckets: one gather of the skew-table bucket, fingerprint match -> candidate position
+//   S5  candidates compacted; one gather of the sequence+boundary record verifies the k-mer and gives
+//       unitig id / offset / length (exact in-order walk only if a flagged item's first candidate fails);
 //       results stored as coalesced 16-byte records
 // ------------------------------------------------------------------------------------
 constexpr int kQpt = 4;                  // queries per thread
