@@ -365,6 +365,74 @@ int mz_sshash_k2u_reads_device(mz_sshash *ix, const uint8_t *d_bases, uint64_t n
                             (hipStream_t)stream);
 }
 
+// Reads through the two-slot staging pipe: a chunk is a run of whole reads whose windows fit the result slot and whose
+// bases + offset tables fit the query slot.  Slot layout: [read offsets (nr+1)][k-mer offsets (nr+1)][bases], rebased to
+// the chunk.  Returns MZ_EUNSUPPORTED_INTERNAL when a single read is too long for a chunk (the caller then takes the
+// unchunked path).
+static const int MZ_EUNSUPPORTED_INTERNAL = -1000;
+static int k2u_reads_pipelined(mz_sshash *ix, const uint8_t *bases, const uint64_t *read_offsets, const uint64_t *ko, uint64_t n_reads,
+                               int streaming, mz_k2upos *out, mz_counts *counts) {
+    // chunk capacity in windows: the configured chunk, or less when the whole call is smaller
+    const uint64_t all_bytes = (read_offsets[n_reads] - read_offsets[0]) + 16 * (n_reads + 1) + 64;
+    const uint64_t cap = std::max<uint64_t>(1, std::min<uint64_t>(host_chunk_queries(), std::max<uint64_t>(ko[n_reads], (all_bytes + 7) / 8)));
+    const uint64_t cap_in = cap * 8;
+    // chunk boundaries
+    std::vector<uint64_t> cut{0};
+    for (uint64_t r0 = 0; r0 < n_reads;) {
+        uint64_t r1 = r0;
+        while (r1 < n_reads) {
+            const uint64_t win = ko[r1 + 1] - ko[r0], bytes = (read_offsets[r1 + 1] - read_offsets[r0]) + 16 * (r1 + 1 - r0 + 1) + 64;
+            if (win > cap || bytes > cap_in) break;
+            ++r1;
+        }
+        if (r1 == r0) return MZ_EUNSUPPORTED_INTERNAL;
+        cut.push_back(r1);
+        r0 = r1;
+    }
+    HostPipe *p = nullptr;
+    int rc = pipe_acquire(ix, cap, &p);
+    if (rc != MZ_OK) return rc;
+    const uint64_t n_chunks = cut.size() - 1;
+    hipError_t e = hipMemsetAsync(p->d_counts, 0, sizeof(mz_counts), p->stream[0]);
+    if (e == hipSuccess) e = hipEventRecord(p->done[0], p->stream[0]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(p->stream[1], p->done[0], 0);
+    for (uint64_t c = 0; c <= n_chunks && e == hipSuccess && rc == MZ_OK; ++c) {
+        const int slot = (int)(c & 1);
+        hipStream_t st = p->stream[slot];
+        if (c < n_chunks) {
+            const uint64_t r0 = cut[c], r1 = cut[c + 1], nr = r1 - r0, nb = read_offsets[r1] - read_offsets[r0];
+            uint64_t *h_ro = p->h_in[slot], *h_ko = h_ro + (nr + 1);
+            uint8_t *h_b = reinterpret_cast<uint8_t *>(h_ko + (nr + 1));
+            for (uint64_t i = 0; i <= nr; ++i) { h_ro[i] = read_offsets[r0 + i] - read_offsets[r0]; h_ko[i] = ko[r0 + i] - ko[r0]; }
+            parallel_copy(h_b, bases + read_offsets[r0], nb);
+            const uint64_t in_bytes = 16 * (nr + 1) + nb, n_win = ko[r1] - ko[r0];
+            uint64_t *d_ro = p->d_in[slot], *d_ko = d_ro + (nr + 1);
+            const uint8_t *d_b = reinterpret_cast<const uint8_t *>(d_ko + (nr + 1));
+            if ((e = hipMemcpyAsync(p->d_in[slot], p->h_in[slot], in_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+            if ((rc = launch_k2u_reads(*ix->dev, d_b, nb, d_ro, d_ko, nr, streaming, p->d_out[slot], p->d_counts, st)) != MZ_OK) break;
+            if (n_win && (e = hipMemcpyAsync(p->h_out[slot], p->d_out[slot], n_win * sizeof(mz_k2upos), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+            if (c + 1 == n_chunks) {
+                if (c >= 1 && (e = hipStreamWaitEvent(st, p->done[slot ^ 1], 0)) != hipSuccess) break;
+                if ((e = hipMemcpyAsync(p->h_counts, p->d_counts, sizeof(mz_counts), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+            }
+            if ((e = hipEventRecord(p->done[slot], st)) != hipSuccess) break;
+        }
+        if (c >= 1) {
+            const uint64_t r0 = cut[c - 1], r1 = cut[c], n_win = ko[r1] - ko[r0];
+            if ((e = hipEventSynchronize(p->done[slot ^ 1])) != hipSuccess) break;
+            if (n_win) parallel_copy(out + ko[r0], p->h_out[slot ^ 1], n_win * sizeof(mz_k2upos));
+        }
+    }
+    if (e != hipSuccess) {
+        set_error("HIP error in k2u_reads: %s", hipGetErrorString(e));
+        rc = MZ_EHIP;
+    }
+    if (rc != MZ_OK) { (void)hipStreamSynchronize(p->stream[0]); (void)hipStreamSynchronize(p->stream[1]); }
+    if (rc == MZ_OK && counts) *counts = *p->h_counts;
+    pipe_release(ix, p);
+    return rc;
+}
+
 int mz_sshash_k2u_reads(mz_sshash *ix, const uint8_t *bases, const uint64_t *read_offsets, uint64_t n_reads, int streaming,
                         mz_k2upos *out, mz_counts *counts) {
     if (!ix || (n_reads && (!bases || !read_offsets))) { set_error("null argument"); return MZ_EINVAL; }
@@ -384,6 +452,10 @@ int mz_sshash_k2u_reads(mz_sshash *ix, const uint8_t *bases, const uint64_t *rea
     std::vector<uint64_t> ro(n_reads + 1);
     for (uint64_t r = 0; r <= n_reads; ++r) ro[r] = read_offsets[r] - base0;
     HIPC(hipSetDevice(ix->dev->device));
+    { // pipelined form (same two-slot staging as mz_sshash_k2u_batch) when every read fits one chunk; else the plain form below
+        int prc = k2u_reads_pipelined(ix, bases, read_offsets, ko.data(), n_reads, streaming, out, counts);
+        if (prc != MZ_EUNSUPPORTED_INTERNAL) return prc;
+    }
     uint8_t *d_b = nullptr;
     uint64_t *d_ro = nullptr, *d_ko = nullptr;
     mz_k2upos *d_o = nullptr;

@@ -394,6 +394,33 @@ def test_host_pointer_batch_walks_several_chunks(yeast, monkeypatch):
     assert got.tobytes() == want[:1].tobytes()
 
 
+def test_host_pointer_reads_walk_several_chunks(yeast, monkeypatch):
+    """mz_sshash_k2u_reads pipelines runs of whole reads through the staging slots; a read too long for a chunk takes the
+    unchunked path; results equal the oracle's walk either way"""
+    k, seqs = yeast
+    ix, orc, _ = both(seqs, k, 15, 16)
+    ix.to_device(0)
+    ref = H.read_fasta(CF_YEAST + ".fa")[0][1]
+    rng = np.random.default_rng(5)
+    reads = []
+    for _ in range(400):
+        a = int(rng.integers(0, len(ref) - 400))
+        reads.append(ref[a:a + int(rng.integers(0, 300))])
+    reads[7] = "ACGTN" * 20
+    bases, ro = reads_fixture([("", r) for r in reads])
+    want, ko, oc = orc.k2u_reads(bases, ro, streaming=False)
+    for chunk in (2048, 5000, 1 << 21):
+        monkeypatch.setenv("MZ_HOST_CHUNK", str(chunk))
+        got, counts = ix.k2u_reads(bases, ro)
+        assert got.tobytes() == want.tobytes() and list(counts) == oc.tolist(), chunk
+    long_reads = [ref[1000:9000], ref[20:90], ref[50000:50100]]  # 7970 windows in one read > chunk of 2048: unchunked path
+    bases, ro = reads_fixture([("", r) for r in long_reads])
+    want, ko, oc = orc.k2u_reads(bases, ro, streaming=False)
+    monkeypatch.setenv("MZ_HOST_CHUNK", "2048")
+    got, counts = ix.k2u_reads(bases, ro)
+    assert got.tobytes() == want.tobytes() and list(counts) == oc.tolist()
+
+
 def test_concurrent_host_threads_on_one_handle(yeast):
     """kphf/mod.rs:105-109 requires Self: Sync: several host threads query one index concurrently (ctypes drops the GIL)"""
     import threading
