@@ -8,40 +8,135 @@ from the index's own unitigs (random orientation), 50 % uniform random negatives
 The index is replicated per GPU, the batch is sharded by rank (weak scaling: fixed queries
 per GPU), and the only collective is the final all-reduce of {n_hit, n_miss} over RCCL.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s-human|s-eighth|s-yeast] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s-human|s-pan|s-eighth|s-yeast] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+`--gpus N` with N > 1 outside a torchrun environment starts the N ranks itself (fresh child processes, before this
+process has made any GPU call) and relays rank 0's JSON line.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
 
-import mazu_amd as M  # noqa: E402
-from mazu_amd import synth  # noqa: E402
-
-B_ALG = 208.0        # algorithmic bytes per k-mer query on the 50/50 mix (SURVEY.md 8(d); table in DESIGN.md)
+B_ALG = 208.0        # algorithmic bytes per k-mer query on the 50/50 mix, reference layout (table in DESIGN.md)
 B_ALG_OWN = 134.0    # same accounting for this repository's layout (DESIGN.md section 4)
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, 8.0 TB/s spec
 
-DEFAULT_BATCH = {"s-tiny": 200_000, "s-yeast": 10_000_000, "s-txome": 50_000_000, "s-eighth": 50_000_000, "s-human": 125_000_000}
+DEFAULT_BATCH = {"s-tiny": 200_000, "s-yeast": 10_000_000, "s-txome": 50_000_000, "s-eighth": 50_000_000, "s-human": 125_000_000,
+                 "s-pan": 125_000_000}
+SHAPE = {"s-human": "GRCh38-shaped", "s-pan": "pan-genome-shaped (120 M unitigs, 9 Gbp)", "s-eighth": "GRCh38/8-shaped",
+         "s-yeast": "yeast-sized", "s-txome": "transcriptome-shaped", "s-tiny": "tiny"}
 
 
 def log(msg):
     print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("MZ_WORKLOAD", "s-human"))
+    ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step")
+    ap.add_argument("--w", type=int, default=15)
+    ap.add_argument("--skew", type=int, default=32)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--neg-kind", default="uniform", choices=["uniform", "sub1"],
+                    help="negatives: NEG-U uniform words (the headline) or NEG-1 positives with one substituted base")
+    ap.add_argument("--neg-frac", type=float, default=0.5, help="fraction of negatives in the query mix (the metric is quoted at 0.5)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-mixes", action="store_true", help="skip the NEG-1 and positives-only side measurements")
+    ap.add_argument("--no-validate", dest="validate", action="store_false",
+                    help="skip the correctness gate (K2U::validate_self on the device, every k-mer in both orientations) before timing")
+    ap.add_argument("--host-build", action="store_true", help="build the index with the multi-threaded host builder instead of on the GPU")
+    ap.add_argument("--mode", default="kmers", choices=["kmers", "reads"],
+                    help="kmers: batched point queries (headline); reads: BASELINE config 3, every window of 150-bp reads "
+                         "through mz_sshash_k2u_reads_device (.as_streaming() semantics)")
+    ap.add_argument("--n-reads", type=int, default=1_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--err-frac", type=float, default=0.5, help="reads mode: fraction of reads with 1%% substitutions")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only rehearse the launch: every rank joins the process group, the tallies are all-reduced, rank 0 prints a JSON line "
+                         "(no index, no GPU work; with MZ_DIST_BACKEND=gloo it runs on a box without GPUs)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`bench.py --gpus N` outside torchrun: start N ranks as fresh child processes (this process has made no GPU call and
+    makes none), rank 0 inherits stdout, the others' stdout goes to stderr; exit non-zero if any rank fails."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench launcher] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def launch_check(args):
+    """the N>1 plumbing without an index: process group, the path's one collective, max-over-ranks timing"""
+    import torch
+    from mazu_amd import dist as D
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    backend = os.environ.get("MZ_DIST_BACKEND", "nccl")
+    dev = None
+    if backend == "nccl":
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPU(s) visible; one process per GPU needs {world}")
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+    D.init(backend, dev)
+    counts = torch.tensor([rank + 1, 10 * (rank + 1), 0], dtype=torch.int64, device=dev or "cpu")
+    D.allreduce_counts(counts)
+    t = D.max_over_ranks(float(rank + 1), dev or "cpu")
+    D.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": backend, "counts": counts.cpu().tolist(), "max_over_ranks": t}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads, target_s=8.0):
     """oracle ('port' of sshash.rs) timed on this box's host cores over a bounded sample: a pilot of
-    1 M queries sizes the sample so that the timed region lasts about `target_s` seconds"""
+    1 M queries sizes the sample so that the timed region lasts about `target_s` seconds; then the single-threaded
+    rate (the reference's own bench loop is single-threaded, bin/kphf/main.rs:273-339) on a smaller sample"""
     os.environ["OMP_NUM_THREADS"] = str(n_threads)  # before libgomp initialises inside liboracle.so
     from oracle import oracle as O
     t0 = time.time()
@@ -56,11 +151,17 @@ def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads, target_s=8.0):
     t0 = time.time()
     out, n_hit = orc.k2u_batch(q_host[:n], n_threads=n_threads)
     dt = time.time() - t0
+    n1 = int(min(n, max(100_000, pilot_rate / max(n_threads, 1) * 3.0)))  # about 3 s on one thread
+    t0 = time.time()
+    orc.k2u_batch(q_host[:n1], n_threads=1)
+    dt1 = time.time() - t0
     touch_bytes = 8.0 * orc.word_touches(q_host[:min(n, 500_000)])[0]  # measured 8-byte words per query, reference layout
-    return out, n_hit, n, n / dt / 1e6, t_build, dt, touch_bytes
+    return dict(out=out, n_hit=n_hit, n=n, rate=n / dt / 1e6, t_build=t_build, dt=dt, touch_bytes=touch_bytes,
+                n_single=n1, ns_single=dt1 / n1 * 1e9)
 
 
-def bench_reads(args, ix, us, dev, rank, world, D):
+# ------------------------------------------------------------------------------------------------ reads mode
+def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
     """BASELINE config 3: reads -> every k-mer window, results identical to independent k2u calls"""
     k = us["k"]
     bases, ro = synth.make_reads(us, args.n_reads, args.read_len, seed=2000 + rank, device=dev, err_frac=args.err_frac)
@@ -116,106 +217,77 @@ def bench_reads(args, ix, us, dev, rank, world, D):
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("MZ_WORKLOAD", "s-human"))
-    ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step")
-    ap.add_argument("--w", type=int, default=15)
-    ap.add_argument("--skew", type=int, default=32)
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--neg-kind", default="uniform", choices=["uniform", "sub1"],
-                    help="negatives: NEG-U uniform words (the headline) or NEG-1 positives with one substituted base")
-    ap.add_argument("--neg-frac", type=float, default=0.5, help="fraction of NEG-U negatives in the query mix (the metric is quoted at 0.5)")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-validate", dest="validate", action="store_false",
-                    help="skip the correctness gate (K2U::validate_self on the device, every k-mer in both orientations) before timing")
-    ap.add_argument("--host-build", action="store_true", help="build the index with the multi-threaded host builder instead of on the GPU")
-    ap.add_argument("--mode", default="kmers", choices=["kmers", "reads"],
-                    help="kmers: batched point queries (headline); reads: BASELINE config 3, every window of 150-bp reads "
-                         "through mz_sshash_k2u_reads_device (.as_streaming() semantics)")
-    ap.add_argument("--n-reads", type=int, default=1_000_000)
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--err-frac", type=float, default=0.5, help="reads mode: fraction of reads with 1%% substitutions")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # before torch, the library or any GPU call
+        sys.exit(self_launch(args, argv))
+    sys.path.insert(0, ROOT)
+    if args.launch_check:
+        return launch_check(args)
+
+    import numpy as np
+    import torch
+    import mazu_amd as M
+    from mazu_amd import synth
+    from mazu_amd import dist as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     n_gpus = world
-    if M.lib.mz_device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: the k2u path has no CPU fallback")
     # one process per GPU; MZ_DIST_BACKEND=gloo lets several ranks share one card to rehearse the N>1 path on a 1-GPU box
     backend = os.environ.get("MZ_DIST_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()  # does not initialise the GPU
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a GPU: the k2u path has no CPU fallback")
+    if backend == "nccl" and n_dev < world:
+        raise SystemExit(f"bench.py --gpus {world}: only {n_dev} GPU(s) visible; one process per GPU needs {world} "
+                         f"(MZ_DIST_BACKEND=gloo rehearses the multi-rank path on fewer cards)")
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    import torch.distributed as dist
-    from mazu_amd import dist as D
     D.init(backend, dev)  # nccl == RCCL on ROCm; no-op for a single process
 
     k = 31
     batch = args.batch or DEFAULT_BATCH[args.workload]
-    # ---- unitig set (same seed on every rank -> identical replica), index build on the host
+    # ---- unitig set (same seed on every rank -> identical replica) and its index, built on this rank's GPU
     t0 = time.time()
     us = synth.make_unitig_set(args.workload, k=k, device=dev)
-    words_h = us["words"].cpu().numpy().view(np.uint64)
-    starts_h = us["starts"].cpu().numpy().view(np.uint64)
     t_gen = time.time() - t0
     t0 = time.time()
-    shared = None
-    if args.host_build and world > 1:  # one host build per node: rank 0 builds and lends the flat index file through /dev/shm
-        shared = f"/dev/shm/mazu_amd_bench_{os.environ.get('MASTER_PORT', '0')}_{args.workload}.mzsshash"
-    if not args.host_build:  # every rank builds its replica on its own GPU (bit-identical arrays; host builder where unsupported)
-        uset = M.UnitigSet.from_packed(words_h, us["total_len"], starts_h, k)
-        ix = M.SSHash.from_unitig_set_on_device(uset, args.w, args.skew, args.seed, device=dev_index)
-        del uset
-    else:
-        if rank == 0:
-            uset = M.UnitigSet.from_packed(words_h, us["total_len"], starts_h, k)
-            ix = M.SSHash.from_unitig_set(uset, args.w, args.skew, args.seed)
-            del uset
-            if shared:
-                ix.save(shared)
-        if world > 1:
-            D.barrier()
-            if rank != 0:
-                ix = M.SSHash.load(shared)
-            D.barrier()
-            if rank == 0:
-                os.unlink(shared)
-    t_build = time.time() - t0
-    t0 = time.time()
-    ix.to_device(dev_index)
+    # every rank builds its own replica (GPU builder: bit-identical arrays on every rank; --host-build: the multi-threaded
+    # host builder); duplicate 31-mers of the random background (a handful at this scale) are broken up and the index rebuilt,
+    # so K2U::validate_self holds with no duplicate at all
+    ix, validate, rebuilds = synth.build_index_unique(us, args.w, args.skew, args.seed, device=dev_index, on_device=not args.host_build,
+                                                      log=log if rank == 0 else None)
     torch.cuda.synchronize(dev)
-    t_upload = time.time() - t0
+    t_build = time.time() - t0
+    words_h = us["words"].cpu().numpy().view(np.uint64)
+    starts_h = us["starts"].cpu().numpy().view(np.uint64)
     log(f"{args.workload}: {us['total_len']} bp, {us['n_unitigs']} unitigs, {ix.n_kmers()} k-mers; gen {t_gen:.1f}s "
-        f"build {t_build:.1f}s upload {t_upload:.1f}s; {ix.n_minimizers()} minimizers, {ix.n_minimizer_occs()} occs, "
+        f"build+validate {t_build:.1f}s ({rebuilds} rebuild(s) for duplicates); {ix.n_minimizers()} minimizers, {ix.n_minimizer_occs()} occs, "
         f"{ix.n_kmers_in_skew_index()} skew k-mers, {ix.device_bytes() / 1e9:.2f} GB in HBM, "
         f"{ix.num_bits() / ix.n_kmers():.2f} bits/k-mer")
-    validate = None
-    if args.validate:
+    if args.validate:  # the correctness gate: every k-mer of every unitig in both orientations, on the device
         t0 = time.time()
         validate = ix.validate_self_report()
-        validate["seconds"] = time.time() - t0
-        log(f"validate_self: {validate}")
-        assert validate["n_fail"] == 0, validate
+        validate["seconds"] = round(time.time() - t0, 3)
+        assert validate["n_fail"] == 0 and validate["n_duplicate"] == 0 and validate["n_kmers"] == ix.n_kmers(), validate
 
     if args.mode == "reads":
-        return bench_reads(args, ix, us, dev, rank, world, D)
+        return bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch)
     # ---- this rank's shard of the query batch, generated in HBM
     q = synth.make_query_mix(ix, us, batch, seed=1000 + rank, device=dev, neg_frac=args.neg_frac, neg_kind=args.neg_kind)
     out = torch.empty(batch * 2, dtype=torch.int64, device=dev)
     counts = torch.zeros(3, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev)
 
-    def step():
-        ix.k2u_batch_device(q, out, counts, stream.cuda_stream)
+    def step(qq=q):
+        ix.k2u_batch_device(qq, out, counts, stream.cuda_stream)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -254,7 +326,7 @@ def main():
             "value": round(value, 2), "unit": "M k-mers/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: synthetic GRCh38-shaped unitig set, SSHash k=31 m={args.w} skew_param={args.skew}, "
+            "config": {"workload": f"{args.workload}: synthetic {SHAPE.get(args.workload, '')} unitig set, SSHash k=31 m={args.w} skew_param={args.skew}, "
                                    f"{batch} queries/GPU/step, {100 - round(100 * args.neg_frac)}/{round(100 * args.neg_frac)} positive/negative" + ("" if args.neg_kind == "uniform" else " (NEG-1 negatives)"),
                        "total_len_bp": us["total_len"], "n_unitigs": us["n_unitigs"], "n_kmers": ix.n_kmers(),
                        "queries_per_gpu_per_step": batch, "index_hbm_gb": round(ix.device_bytes() / 1e9, 3),
@@ -266,27 +338,48 @@ def main():
                          "traffic_gbs": round(traffic / avg_kernel_s / 1e9, 1) if traffic else None,
                          "kernel": {"v1": "k2u_batch_kernel", "tile": "k2u_tile_kernel"}.get(os.environ.get("MZ_K2U_KERNEL", ""), "k2u_wave_kernel"), "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_kmer": B_ALG},
-            "build": {"gen_s": round(t_gen, 2), "where": "host" if args.host_build else "gpu", "build_s": round(t_build, 2), "upload_s": round(t_upload, 2),
-                      "bits_per_kmer": round(ix.num_bits() / ix.n_kmers(), 2)},
+            "build": {"gen_s": round(t_gen, 2), "where": "host" if args.host_build else "gpu", "build_and_validate_s": round(t_build, 2),
+                      "rebuilds_for_duplicates": rebuilds, "bits_per_kmer": round(ix.num_bits() / ix.n_kmers(), 2)},
         }
         if validate is not None:
             res["validate_self"] = validate
+        if not args.no_extra_mixes and args.neg_frac == 0.5 and args.neg_kind == "uniform":
+            # the realistic mixes beside the headline: NEG-1 negatives (a positive with one substituted base: shares minimizer and
+            # flanks, so it reaches the k-mer verification) and positives only; same batch size, a few steps each
+            mixes = {"neg_u_50_50": round(value, 2)}
+            for name, kw in (("neg_1_50_50", dict(neg_frac=0.5, neg_kind="sub1")), ("positives_only", dict(neg_frac=0.0, neg_kind="uniform"))):
+                q2 = synth.make_query_mix(ix, us, batch, seed=3000 + rank, device=dev, **kw)
+                step(q2)
+                torch.cuda.synchronize(dev)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n_extra = max(3, min(args.steps, 10))
+                a.record(stream)
+                for _ in range(n_extra):
+                    step(q2)
+                b.record(stream)
+                torch.cuda.synchronize(dev)
+                mixes[name] = round(batch * n_extra / (a.elapsed_time(b) / 1e3) / 1e6, 2)
+                del q2
+            res["mixes_M_kmers_per_s_one_gpu"] = mixes
+            step()  # `out` holds the headline batch's results again for the parity check below
+            torch.cuda.synchronize(dev)
         if n_gpus == 1 and not args.no_cpu_baseline:
             cores = M.lib.mz_host_threads()  # hardware threads capped by the cgroup CPU quota of this box
             q_host = q[: (args.cpu_sample or batch)].cpu().numpy().view(np.uint64)
-            want, orc_hits, n_sample, cpu_rate, t_ob, t_q, touch_bytes = cpu_baseline((words_h, us["total_len"], starts_h), k, args.w, args.skew,
-                                                                       args.seed, q_host, cores)
-            got = out[: 2 * n_sample].cpu().numpy().view(M.K2UPOS_DTYPE)
-            same = got.tobytes() == want.tobytes()
-            res["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "M k-mers/s", "cores": cores, "kind": "port",
-                                   "sample": f"first {n_sample} queries of the rank-0 batch on the same {args.workload} index, "
-                                             f"OpenMP static shards over {cores} threads (oracle build {t_ob:.1f}s, query {t_q:.1f}s)",
+            cb = cpu_baseline((words_h, us["total_len"], starts_h), k, args.w, args.skew, args.seed, q_host, cores)
+            got = out[: 2 * cb["n"]].cpu().numpy().view(M.K2UPOS_DTYPE)
+            same = got.tobytes() == cb["out"].tobytes()
+            res["cpu_baseline"] = {"value": round(cb["rate"], 3), "unit": "M k-mers/s", "cores": cores, "kind": "port",
+                                   "sample": f"first {cb['n']} queries of the rank-0 batch on the same {args.workload} index, "
+                                             f"OpenMP static shards over {cores} threads (oracle build {cb['t_build']:.1f}s, query {cb['dt']:.1f}s)",
+                                   "single_thread_ns_per_kmer": round(cb["ns_single"], 1),
+                                   "single_thread_sample": f"first {cb['n_single']} queries, one thread (the reference's bench loop, bin/kphf/main.rs:273-339, is single-threaded)",
                                    "results_identical_to_gpu": same,
-                                   "word_touch_bytes_per_kmer": round(touch_bytes, 1)}
-            res["gpu_over_cpu"] = round(value / cpu_rate, 1)
+                                   "word_touch_bytes_per_kmer": round(cb["touch_bytes"], 1)}
             assert same, "GPU results differ from the CPU oracle on the sampled queries"
         print(json.dumps(res), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -139,6 +139,9 @@ uint64_t mz_sshash_n_minimizers(const mz_sshash *ix);
 uint64_t mz_sshash_n_minimizer_occs(const mz_sshash *ix);
 uint64_t mz_sshash_n_kmers_in_skew_index(const mz_sshash *ix);
 uint64_t mz_sshash_num_bits(const mz_sshash *ix);
+/* form of the minimizer MPHF (the reference's boomphf, sshash.rs:177): 1 = direct-address minimizer records (2w <= 32 and
+ * the record table small next to the key set), 0 = BBHash levels */
+uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix);
 /* bytes resident in HBM once uploaded */
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix);
 
@@ -177,6 +180,10 @@ int mz_sshash_k2u_reads_device(mz_sshash *ix, const uint8_t *d_bases, uint64_t n
 /* K2U::validate_self / validate_self_parallel, kphf/mod.rs:69-139, run on the device: every k-mer of
  * every unitig is queried in both orientations and compared with (unitig, offset, len, Identity|Twin). */
 int mz_sshash_validate_self(mz_sshash *ix, mz_validate_report *report);
+/* same pass; additionally lists up to `cap` global base positions of k-mers counted in n_duplicate (the copy the lookup
+ * does NOT answer with), in no particular order; *n_listed (may be NULL) receives how many were written.  For inputs that
+ * are not a cdBG (UnitigSet::from_seqs on arbitrary strings, unitig_set.rs:74-106) this says where the repeats are. */
+int mz_sshash_validate_self_duplicates(mz_sshash *ix, mz_validate_report *report, uint64_t *dup_pos, uint64_t cap, uint64_t *n_listed);
 
 /* forward words of the k-mers at global positions (device arrays); flip[i] != 0 returns the reverse
  * complement instead.  Used to synthesise positive queries without leaving HBM. */

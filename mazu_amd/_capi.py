@@ -75,6 +75,7 @@ def _load():
         "mz_sshash_n_minimizer_occs": (u64, [p]),
         "mz_sshash_n_kmers_in_skew_index": (u64, [p]),
         "mz_sshash_num_bits": (u64, [p]),
+        "mz_sshash_minimizer_mphf_kind": (u32, [p]),
         "mz_sshash_device_bytes": (u64, [p]),
         "mz_sshash_to_device": (i, [p, i]),
         "mz_sshash_k2u": (i, [p, u64, u32, p]),
@@ -85,6 +86,7 @@ def _load():
         "mz_sshash_k2u_reads": (i, [p, p, p, u64, i, p, p]),
         "mz_sshash_k2u_reads_device": (i, [p, p, u64, p, p, u64, i, p, p, p]),
         "mz_sshash_validate_self": (i, [p, p]),
+        "mz_sshash_validate_self_duplicates": (i, [p, p, p, u64, p]),
         "mz_sshash_extract_kmers_device": (i, [p, p, p, u64, p, p]),
         "mz_sshash_save": (i, [p, C.c_char_p]),
         "mz_sshash_load": (i, [C.c_char_p, p]),

@@ -11,7 +11,9 @@
 //   G4  skew index: k-mers around heavy minimizers, sort/unique, hash table of 128-byte buckets (stable sort by home
 //       bucket, rank inside the bucket, overflow list)
 // Restrictions (otherwise the caller falls back to the host builder): direct-address minimizer records
-// (2w <= 32) and 2w + bit_len(total_len) + 1 <= 64 so that an occurrence fits one 64-bit sort key.
+// (2w <= 32) and an occurrence (word, position, strand class) must fit one 64-bit sort key: 2w + bit_len(total_len) + 1
+// <= 64, or one bit more for odd w, where the class is implied (no w-mer of odd length equals its reverse complement, so
+// the class is 1 exactly when the forward w-mer at the position differs from the word) and is left out of the key.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -32,11 +34,13 @@
 
 namespace mz {
 
+// hipErrorOutOfMemory is reported as MZ_ENOMEM (and cleared), so the caller can fall back to the host builder
 #define BG_HIP(expr)                                                                                  \
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \
         if (_e != hipSuccess) {                                                                       \
             set_error("HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+            if (_e == hipErrorOutOfMemory) { (void)hipGetLastError(); return MZ_ENOMEM; }             \
             return MZ_EHIP;                                                                           \
         }                                                                                             \
     } while (0)
@@ -65,8 +69,15 @@ struct ScanParams {
     const uint64_t *useq;   // plain packed sequence (+2 pad words)
     const uint64_t *seqbv;  // interleaved records (unitig boundaries)
     uint64_t total_len, seed;
-    uint32_t k, w, key_shift; // key = (word << key_shift) | (pos << 1) | cls
+    uint32_t k, w, key_shift; // key = (word << key_shift) | (pos << cls_bits) | (cls if cls_bits)
+    uint32_t cls_bits;        // 1: strand class kept in the key's lowest bit; 0: implied (odd w only), see key_pos_cls()
 };
+// position and strand class of an occurrence key
+__device__ __forceinline__ void key_pos_cls(const ScanParams &P, uint64_t key, uint64_t &pos, uint32_t &cls) {
+    const uint64_t pc = key & ((1ull << P.key_shift) - 1);
+    pos = pc >> P.cls_bits;
+    cls = P.cls_bits ? (uint32_t)(pc & 1) : (uint32_t)(read_kmer(P.useq, pos, P.w) != (key >> P.key_shift));
+}
 
 // G1: one key per k-mer start position; a key is kept when it differs from its left neighbour's (the
 // reference drops consecutive duplicates per strand class, sshash.rs:109-134; the unique pass after the sort
@@ -101,13 +112,13 @@ __global__ __launch_bounds__(kB) void scan_minimizers_kernel(ScanParams P, uint6
                         uint32_t bo = 0;
                         uint64_t bh = hf[i];
                         for (uint32_t o = 1; o < n_win; ++o) { uint64_t h = hf[i + o]; if (h < bh) { bh = h; bo = o; } }
-                        key = (((fw >> (2 * bo)) & kmer_mask(w)) << P.key_shift) | ((p + bo) << 1);
+                        key = (((fw >> (2 * bo)) & kmer_mask(w)) << P.key_shift) | ((p + bo) << P.cls_bits);
                     } else { // reverse-canonical: rightmost minimum of the reverse hashes; word of g* = rc of the forward w-mer
                         uint32_t bj = 0;
                         uint64_t bh = hr[i];
                         for (uint32_t j = 1; j < n_win; ++j) { uint64_t h = hr[i + j]; if (h <= bh) { bh = h; bj = j; } }
                         const uint32_t og = (k - w) - bj; // offset inside g* = rc
-                        key = (((rc >> (2 * og)) & kmer_mask(w)) << P.key_shift) | ((p + bj) << 1) | 1u;
+                        key = (((rc >> (2 * og)) & kmer_mask(w)) << P.key_shift) | ((p + bj) << P.cls_bits) | P.cls_bits;
                     }
                 }
             }
@@ -239,13 +250,14 @@ __global__ __launch_bounds__(kB) void bef_overflow_kernel(const uint64_t *__rest
 __global__ __launch_bounds__(kB) void pos_entries_kernel(const uint64_t *__restrict__ keys, uint64_t n, ScanParams P, uint32_t width, uint64_t n_words,
                                                          uint64_t *__restrict__ packed) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
-    const uint64_t pmask = (1ull << P.key_shift) - 1;
     for (uint64_t wi = (uint64_t)blockIdx.x * kB + threadIdx.x; wi < n_words; wi += stride) {
         const uint64_t bit0 = wi * 64;
         uint64_t word = 0;
         for (uint64_t i = bit0 / width; i < n && i * width < bit0 + 64; ++i) {
-            const uint64_t pc = keys[i] & pmask, pos = pc >> 1;
-            const uint64_t ent = make_entry(pos, (uint32_t)(pc & 1), flank_of(P.useq, P.total_len, pos, P.w));
+            uint64_t pos;
+            uint32_t cls;
+            key_pos_cls(P, keys[i], pos, cls);
+            const uint64_t ent = make_entry(pos, cls, flank_of(P.useq, P.total_len, pos, P.w));
             const uint64_t b = i * width;
             word |= b >= bit0 ? ent << (b - bit0) : ent >> (bit0 - b);
         }
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(kB) void skew_tuples_kernel(const uint64_t *__restr
             uint64_t word = 0, p = 0;
             if (x < items) {
                 const uint64_t occ = x / span, off = x - occ * span;
-                const uint64_t mp = (keys[s + occ] & pmask) >> 1;
+                const uint64_t mp = (keys[s + occ] & pmask) >> P.cls_bits;
                 const uint64_t start_pos = mp < (uint64_t)(k - w) ? 0 : mp - (k - w);
                 p = start_pos + off;
                 if (p + k <= P.total_len) {
@@ -301,13 +313,13 @@ __global__ __launch_bounds__(kB) void skew_tuples_kernel(const uint64_t *__restr
 }
 
 // ---- skew table (SkewTable::build of the host) ----
-__global__ __launch_bounds__(kB) void skew_home_kernel(const uint64_t *__restrict__ words, uint64_t n, uint64_t n_buckets, uint64_t *__restrict__ hb,
-                                                       uint64_t *__restrict__ idx) {
+__global__ __launch_bounds__(kB) void skew_home_kernel(const uint64_t *__restrict__ words, uint64_t n, uint64_t n_buckets, uint32_t fp_mask,
+                                                       uint64_t *__restrict__ hb, uint64_t *__restrict__ idx) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
     for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) {
         uint64_t b;
         uint32_t fp;
-        skew_home(words[i], n_buckets, b, fp);
+        skew_home(words[i], n_buckets, fp_mask, b, fp);
         hb[i] = b;
         idx[i] = i;
     }
@@ -318,13 +330,13 @@ __global__ __launch_bounds__(kB) void skew_heads_kernel(const uint64_t *__restri
 }
 __global__ __launch_bounds__(kB) void skew_place_kernel(const uint64_t *__restrict__ hb, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ first,
                                                         const uint64_t *__restrict__ words, const uint64_t *__restrict__ pos, uint64_t n, uint64_t n_buckets,
-                                                        uint64_t *__restrict__ table, uint8_t *__restrict__ ovflag) {
+                                                        uint32_t fp_mask, uint64_t *__restrict__ table, uint8_t *__restrict__ ovflag) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
     for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < n; j += stride) {
         const uint64_t rank = j - first[j], i = idx[j];
         uint64_t b;
         uint32_t fp;
-        skew_home(words[i], n_buckets, b, fp);
+        skew_home(words[i], n_buckets, fp_mask, b, fp);
         if (rank < kSkewSlots) table[hb[j] * kSkewSlots + rank] = skew_slot(fp, pos[i]);
         ovflag[j] = rank >= kSkewSlots;
     }
@@ -366,7 +378,7 @@ int download(std::vector<T> &dst, const T *src, uint64_t n) {
 
 bool gpu_build_supported(const UnitigSet &us, uint32_t w) {
     if (w == 0 || w > us.k || 2 * w > 32) return false;
-    if (2 * w + bit_len(us.total_len) + 1 > 64) return false;
+    if (2 * w + bit_len(us.total_len) + ((w & 1) ? 0 : 1) > 64) return false;
     uint64_t rec_bytes = (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords * 8;
     return rec_bytes <= (8ull << 30); // the host rule additionally needs >= rec_bytes/16 minimizers; checked after G2
 }
@@ -394,7 +406,9 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
     BG_HIP(hipMemcpy(d_useq, us.useq.data(), us.useq.size() * 8, hipMemcpyHostToDevice));
     BG_HIP(hipMemcpy(d_seqbv, us.seqbv.data(), us.seqbv.size() * 8, hipMemcpyHostToDevice));
     P.useq = d_useq; P.seqbv = d_seqbv; P.total_len = us.total_len; P.seed = seed; P.k = k; P.w = w;
-    P.key_shift = bit_len(us.total_len) + 1;
+    P.cls_bits = 2 * w + bit_len(us.total_len) + 1 <= 64 ? 1u : 0u;
+    if ((w & 1) && std::getenv("MZ_TEST_GPU_BUILD_IMPLIED_CLASS")) P.cls_bits = 0; // tests walk the implied-class form on small sets
+    P.key_shift = bit_len(us.total_len) + P.cls_bits;
     phase("upload sequence");
 
     // ---- G1: count, then store
@@ -534,6 +548,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         // skew table over d_tw2[0..sn) (word order) / d_tp2 (SkewTable::build of the host)
         SkewTable &st = h.skew;
         st.n_keys = sn;
+        st.fp_bits = skew_fp_bits_for_build();
         st.n_buckets = sn ? (sn + kSkewLoad - 1) / kSkewLoad : 0;
         st.ovf_word.clear();
         st.ovf_pos.clear();
@@ -544,12 +559,12 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
             BG_HIP(buf.alloc(&d_tab, n_slots));
             BG_HIP(buf.alloc(&d_hb2, sn)); BG_HIP(buf.alloc(&d_ix2, sn)); BG_HIP(buf.alloc(&d_first, sn)); BG_HIP(buf.alloc(&d_ovflag, sn));
             BG_HIP(hipMemset(d_tab, 0xFF, n_slots * 8));
-            hipLaunchKernelGGL(skew_home_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_tw2, sn, st.n_buckets, d_hb, d_ix);
+            hipLaunchKernelGGL(skew_home_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_tw2, sn, st.n_buckets, st.fp_mask(), d_hb, d_ix);
             // stable sort by home bucket: the keys of a bucket stay in word order
             ROCPRIM_RUN(buf, rocprim::radix_sort_pairs(tmp, tmp_bytes, d_hb, d_hb2, d_ix, d_ix2, sn, 0, bit_len(st.n_buckets)));
             hipLaunchKernelGGL(skew_heads_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_hb2, sn, d_hb); // d_hb reused: head positions
             ROCPRIM_RUN(buf, rocprim::inclusive_scan(tmp, tmp_bytes, d_hb, d_first, sn, rocprim::maximum<uint64_t>()));
-            hipLaunchKernelGGL(skew_place_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_hb2, d_ix2, d_first, d_tw2, d_tp2, sn, st.n_buckets, d_tab, d_ovflag);
+            hipLaunchKernelGGL(skew_place_kernel, dim3(grid_of(sn)), dim3(kB), 0, 0, d_hb2, d_ix2, d_first, d_tw2, d_tp2, sn, st.n_buckets, st.fp_mask(), d_tab, d_ovflag);
             ROCPRIM_RUN(buf, rocprim::select(tmp, tmp_bytes, d_ix2, d_ovflag, d_ix, d_nsel, sn)); // d_ix reused: overflowed key indices, in (bucket, word) order
             uint64_t n_ovf = 0;
             BG_HIP(hipMemcpy(&n_ovf, d_nsel, 8, hipMemcpyDeviceToHost));

@@ -3,8 +3,10 @@
 // lazily created per-device replica.  All query work is done by the kernels in mz_device.hip.
 #include <hip/hip_runtime_api.h>
 
+#include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <exception>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -97,6 +99,12 @@ static int replica_for_pointer(mz_sshash *ix, const void *dptr, DeviceIndex **ou
     return rc;
 }
 
+int mz_internal_default_device(mz_sshash *ix, int *device) {
+    int rc = ensure_device(ix);
+    if (rc == MZ_OK) *device = ix->dev->device;
+    return rc;
+}
+
 extern "C" {
 
 const char *mz_last_error(void) { return last_error(); }
@@ -151,6 +159,7 @@ int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew
     return MZ_OK;
 }
 int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int device, mz_sshash **out) {
+    DeviceGuard guard;
     if (!us || !out) { set_error("null argument"); return MZ_EINVAL; }
     *out = nullptr;
     if (w == 0 || w > us->us.k) { set_error("SSHash: minimizer size w=%u must be in 1..=k (k=%u)", w, us->us.k); return MZ_EINVAL; }
@@ -159,6 +168,11 @@ int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64
     int rc = MZ_EINVAL;
     try {
         if (gpu_build_supported(us->us, w)) rc = build_on_device(ix->host, us->us, w, skew_param, seed, device);
+        if (rc == MZ_ENOMEM) { // the device ran out of memory next to what already lives there: the host builder can still do it
+            std::fprintf(stderr, "[mazu_amd] GPU index build ran out of device memory (%s); building on the host instead\n", last_error());
+            ix->host = SSHashHost();
+            rc = MZ_EINVAL;
+        }
         if (rc == MZ_EINVAL) rc = ix->host.build(us->us, w, skew_param, seed, 0); // configuration left to the host builder
     } catch (const std::bad_alloc &) {
         set_error("out of host memory while building the index");
@@ -170,6 +184,7 @@ int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64
 }
 void mz_sshash_free(mz_sshash *ix) {
     if (!ix) return;
+    DeviceGuard guard;
     for (HostPipe *p : ix->idle_pipes) { p->release(); delete p; }
     for (DeviceIndex *r : ix->replicas) device_free(r);
     delete ix;
@@ -197,9 +212,11 @@ uint64_t mz_sshash_n_minimizers(const mz_sshash *ix) { return ix->host.n_minimiz
 uint64_t mz_sshash_n_minimizer_occs(const mz_sshash *ix) { return ix->host.pos.n; }
 uint64_t mz_sshash_n_kmers_in_skew_index(const mz_sshash *ix) { return ix->host.has_skew ? ix->host.skew.n_keys : 0; }
 uint64_t mz_sshash_num_bits(const mz_sshash *ix) { return ix->host.num_bits(); }
+uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix) { return ix->host.mm.direct ? 1u : 0u; }
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix) { return ix->dev ? ix->dev->bytes : 0; } /* per replica */
 
 int mz_sshash_to_device(mz_sshash *ix, int device) {
+    DeviceGuard guard;
     if (!ix) { set_error("null index"); return MZ_EINVAL; }
     DeviceIndex *r = nullptr;
     int rc = replica_on(ix, device, &r);
@@ -210,6 +227,7 @@ int mz_sshash_to_device(mz_sshash *ix, int device) {
 
 int mz_sshash_k2u_batch_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
                                void *stream) {
+    DeviceGuard guard;
     if (!ix || (n && (!d_fw_words || !d_out))) { set_error("null argument"); return MZ_EINVAL; }
     DeviceIndex *r = nullptr;
     int rc = replica_for_pointer(ix, d_out, &r);
@@ -219,6 +237,7 @@ int mz_sshash_k2u_batch_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64
 
 int mz_sshash_k2u_batch_compact_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64_t n, uint64_t *d_hit_idx,
                                        mz_k2upos *d_hits, uint64_t *d_n_hits, void *stream) {
+    DeviceGuard guard;
     if (!ix || !d_n_hits || (n && (!d_fw_words || !d_hit_idx || !d_hits))) { set_error("null argument"); return MZ_EINVAL; }
     DeviceIndex *r = nullptr;
     int rc = replica_for_pointer(ix, d_n_hits, &r);
@@ -290,6 +309,7 @@ static void pipe_release(mz_sshash *ix, HostPipe *p) {
 // Host pointers in, host pointers out.  Chunks go through two pinned slots: while the GPU works on chunk c (H2D, kernel,
 // D2H on one stream) the calling thread drains the results of chunk c-1 into `out` and stages the queries of chunk c+1.
 int mz_sshash_k2u_batch(mz_sshash *ix, const uint64_t *fw_words, uint64_t n, mz_k2upos *out, mz_counts *counts) {
+    DeviceGuard guard;
     if (!ix || (n && (!fw_words || !out))) { set_error("null argument"); return MZ_EINVAL; }
     int rc = ensure_device(ix);
     if (rc != MZ_OK) return rc;
@@ -357,6 +377,7 @@ uint64_t mz_reads_n_windows(const uint64_t *read_offsets, uint64_t n_reads, uint
 int mz_sshash_k2u_reads_device(mz_sshash *ix, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
                                const uint64_t *d_kmer_offsets, uint64_t n_reads, int streaming, mz_k2upos *d_out,
                                mz_counts *d_counts, void *stream) {
+    DeviceGuard guard;
     if (!ix || (n_reads && (!d_bases || !d_read_offsets || !d_kmer_offsets || !d_out))) { set_error("null argument"); return MZ_EINVAL; }
     DeviceIndex *r = nullptr;
     int rc = replica_for_pointer(ix, d_read_offsets, &r);
@@ -435,6 +456,7 @@ static int k2u_reads_pipelined(mz_sshash *ix, const uint8_t *bases, const uint64
 
 int mz_sshash_k2u_reads(mz_sshash *ix, const uint8_t *bases, const uint64_t *read_offsets, uint64_t n_reads, int streaming,
                         mz_k2upos *out, mz_counts *counts) {
+    DeviceGuard guard;
     if (!ix || (n_reads && (!bases || !read_offsets))) { set_error("null argument"); return MZ_EINVAL; }
     int rc = ensure_device(ix);
     if (rc != MZ_OK) return rc;
@@ -495,17 +517,19 @@ int mz_sshash_k2u_reads(mz_sshash *ix, const uint8_t *bases, const uint64_t *rea
     return rc;
 }
 
-int mz_sshash_validate_self(mz_sshash *ix, mz_validate_report *report) {
-    if (!ix || !report) { set_error("null argument"); return MZ_EINVAL; }
+int mz_sshash_validate_self_duplicates(mz_sshash *ix, mz_validate_report *report, uint64_t *dup_pos, uint64_t cap, uint64_t *n_listed) {
+    DeviceGuard guard;
+    if (!ix || !report || (cap && !dup_pos)) { set_error("null argument"); return MZ_EINVAL; }
     int rc = ensure_device(ix);
     if (rc != MZ_OK) return rc;
     HIPC(hipSetDevice(ix->dev->device));
-    uint64_t init[4] = {0, 0, 0, ~0ull}, *d_r = nullptr;
-    HIPC(hipMalloc((void **)&d_r, sizeof init));
+    uint64_t init[5] = {0, 0, 0, ~0ull, 0}, *d_r = nullptr; // report words followed by the duplicate list
+    HIPC(hipMalloc((void **)&d_r, sizeof init + cap * 8));
     hipError_t e = hipMemcpy(d_r, init, sizeof init, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = launch_validate_self(*ix->dev, d_r, nullptr);
+        rc = launch_validate_self(*ix->dev, d_r, cap ? d_r + 5 : nullptr, cap, nullptr);
         if (rc == MZ_OK) e = hipMemcpy(init, d_r, sizeof init, hipMemcpyDeviceToHost); // synchronises with the null stream
+        if (rc == MZ_OK && e == hipSuccess && cap && init[4]) e = hipMemcpy(dup_pos, d_r + 5, std::min<uint64_t>(init[4], cap) * 8, hipMemcpyDeviceToHost);
     }
     (void)hipFree(d_r);
     if (e != hipSuccess) { set_error("HIP error in validate_self: %s", hipGetErrorString(e)); return MZ_EHIP; }
@@ -514,11 +538,14 @@ int mz_sshash_validate_self(mz_sshash *ix, mz_validate_report *report) {
     report->n_fail = init[1];
     report->n_duplicate = init[2];
     report->first_fail_pos = init[3];
+    if (n_listed) *n_listed = std::min<uint64_t>(init[4], cap);
     return MZ_OK;
 }
+int mz_sshash_validate_self(mz_sshash *ix, mz_validate_report *report) { return mz_sshash_validate_self_duplicates(ix, report, nullptr, 0, nullptr); }
 
 int mz_sshash_extract_kmers_device(mz_sshash *ix, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
                                    uint64_t *d_fw_words, void *stream) {
+    DeviceGuard guard;
     if (!ix || (n && (!d_positions || !d_fw_words))) { set_error("null argument"); return MZ_EINVAL; }
     DeviceIndex *r = nullptr;
     int rc = replica_for_pointer(ix, d_fw_words, &r);
@@ -535,7 +562,16 @@ int mz_sshash_load(const char *path, mz_sshash **out) {
     *out = nullptr;
     mz_sshash *ix = new (std::nothrow) mz_sshash();
     if (!ix) return MZ_ENOMEM;
-    int rc = ix->host.load(path);
+    int rc;
+    try {
+        rc = ix->host.load(path);
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory while loading %s", path);
+        rc = MZ_ENOMEM;
+    } catch (const std::exception &e) {
+        set_error("%s: %s", path, e.what());
+        rc = MZ_EIO;
+    }
     if (rc != MZ_OK) { delete ix; return rc; }
     *out = ix;
     return MZ_OK;
@@ -549,31 +585,22 @@ int mz_streaming_new(mz_sshash *ix, mz_streaming **out) {
 }
 void mz_streaming_free(mz_streaming *st) { delete st; }
 
-// index/caching.rs:65-103.  The warm check is the same packed-sequence comparison the reads
-// kernel performs; it is evaluated on the device as a one-position extract so that no k-mer
-// comparison is ever answered from host memory.
+// index/caching.rs:65-103.  The warm step compares the query with the k-mer that follows the previous hit on its unitig,
+// read from the handle's own packed unitig sequence (the UnitigSet the reference's StreamingK2U borrows through
+// AsRef<UnitigSet>, caching.rs:43-46,84-87): two host words, no device call.  Everything else is a cold lookup on the GPU.
 int mz_streaming_k2u(mz_streaming *st, uint64_t fw_word, uint32_t k, mz_k2upos *out) {
+    DeviceGuard guard;
     if (!st || !out) { set_error("null argument"); return MZ_EINVAL; }
     mz_sshash *ix = st->ix;
     if (k != ix->host.us.k) { set_error("Got query k-mer size k=%u, expected k=%u.", k, ix->host.us.k); return MZ_EINVAL; }
-    int rc = ensure_device(ix);
-    if (rc != MZ_OK) return rc;
+    int rc = MZ_OK;
     fw_word &= kmer_mask(k);
     if (st->is_warm) { // k2u_warm, :73-97
-        uint64_t next_pos = (uint64_t)st->prev.pos + 1, last_km_pos = (uint64_t)st->prev.unitig_len - k;
+        const uint64_t next_pos = (uint64_t)st->prev.pos + 1, last_km_pos = (uint64_t)st->prev.unitig_len - k;
         if (next_pos <= last_km_pos) {
-            HIPC(hipSetDevice(ix->dev->device));
-            uint64_t gp = ix->host.us.unitig_start_pos(st->prev.unitig_id) + next_pos, kw = 0, *d = nullptr;
-            HIPC(hipMalloc((void **)&d, 16));
-            hipError_t e = hipMemcpy(d, &gp, 8, hipMemcpyHostToDevice);
-            if (e == hipSuccess) {
-                rc = launch_extract_kmers(*ix->dev, d, nullptr, 1, d + 1, nullptr);
-                if (rc == MZ_OK) e = hipMemcpy(&kw, d + 1, 8, hipMemcpyDeviceToHost);
-            }
-            (void)hipFree(d);
-            if (e != hipSuccess) { set_error("HIP error in streaming k2u: %s", hipGetErrorString(e)); return MZ_EHIP; }
-            if (rc != MZ_OK) return rc;
-            uint32_t mt = kw == fw_word ? MZ_IDENTITY_MATCH : (kw == kmer_rc(fw_word, k) ? MZ_TWIN_MATCH : MZ_NO_MATCH);
+            const uint64_t gp = ix->host.us.starts[st->prev.unitig_id] + next_pos;
+            const uint64_t kw = read_kmer(ix->host.us.useq.data(), gp, k);
+            const uint32_t mt = word_equivalency(fw_word, kmer_rc(fw_word, k), kw);
             if (mt != MZ_NO_MATCH) {
                 st->prev.pos = (uint32_t)next_pos;
                 st->prev.match = mt;

@@ -349,6 +349,7 @@ struct SkewView {
     const uint64_t *ovf_word;  // overflowed keys, sorted by (home bucket, word)
     const uint64_t *ovf_pos;
     uint64_t n_buckets, n_ovf, n_keys;
+    uint32_t fp_mask, pad;     // (1 << fingerprint bits) - 1; kSkewFpBits unless a test narrowed it to force collisions
 };
 MZ_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -649,10 +650,10 @@ MZ_HD mz_k2upos make_hit(const UnitigSpan &s, uint64_t km_pos, uint32_t mt) {
 
 // sshash.rs:415-433 + SkewIndex::lookup :59-66
 // home bucket and fingerprint of a canonical k-mer word
-MZ_HD void skew_home(uint64_t word, uint64_t n_buckets, uint64_t &bucket, uint32_t &fp) {
+MZ_HD void skew_home(uint64_t word, uint64_t n_buckets, uint32_t fp_mask, uint64_t &bucket, uint32_t &fp) {
     const uint64_t h = mum(word ^ kSkewSeed, kP1);
     bucket = mulhi64(h ^ (h >> 32), n_buckets);
-    fp = (uint32_t)h & ((1u << kSkewFpBits) - 1);
+    fp = (uint32_t)h & fp_mask;
 }
 MZ_HD uint64_t skew_slot(uint32_t fp, uint64_t pos) { return ((uint64_t)fp << kSkewPosBits) | pos; }
 // exact lookup (every slot with the k-mer's fingerprint is verified, then the overflow list): sshash.rs:415-433 + :59-66
@@ -661,7 +662,7 @@ MZ_HD mz_k2upos skew_lookup(const IndexView &ix, uint64_t fw, uint64_t rc) {
     const uint64_t word = fw < rc ? fw : rc;
     uint64_t b;
     uint32_t fp;
-    skew_home(word, ix.skew.n_buckets, b, fp);
+    skew_home(word, ix.skew.n_buckets, ix.skew.fp_mask, b, fp);
     const uint64_t *B = ix.skew.buckets + b * kSkewSlots;
     uint32_t used = 0;
     for (; used < kSkewSlots; ++used) {
@@ -678,7 +679,7 @@ MZ_HD mz_k2upos skew_lookup(const IndexView &ix, uint64_t fw, uint64_t rc) {
         const uint64_t mid = (lo + hi) >> 1, mw = ix.skew.ovf_word[mid];
         uint64_t mb;
         uint32_t mf;
-        skew_home(mw, ix.skew.n_buckets, mb, mf);
+        skew_home(mw, ix.skew.n_buckets, ix.skew.fp_mask, mb, mf);
         if (mb < b || (mb == b && mw < word)) lo = mid + 1; else hi = mid;
     }
     if (lo < ix.skew.n_ovf && ix.skew.ovf_word[lo] == word) {

@@ -516,8 +516,9 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     SC::sync();
     if constexpr (kStopAfter == 3) return;
     // ---- S4: heavy buckets go through the skew index (sshash.rs:415-433): ONE gather of the k-mer's 128-byte home bucket;
-    //          the slot with its fingerprint gives the candidate position for S5.  More than one such slot, or none in a
-    //          full bucket (its keys may have overflowed), only raises the item's flag: S5 then falls back to the exact walk.
+    //          the slot with its fingerprint gives the candidate position for S5.  More than one such slot, or a full
+    //          bucket (its keys may have overflowed), raises the item's flag: if S5 cannot verify the candidate it falls
+    //          back to the exact walk, which also searches the overflow list.
     if (S.cnt_skew != 0) { // uniform
         const uint32_t ns = S.cnt_skew;
         SC::sync();
@@ -527,7 +528,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
                 uint64_t hb;
                 uint32_t fp;
-                skew_home(fw < rc ? fw : rc, ix.skew.n_buckets, hb, fp);
+                skew_home(fw < rc ? fw : rc, ix.skew.n_buckets, ix.skew.fp_mask, hb, fp);
                 const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(ix.skew.buckets + hb * kSkewSlots);
                 ulonglong2 sl[kSkewSlots / 2];
 #pragma unroll
@@ -541,7 +542,9 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                     if (e == kSkewEmpty) full = false;
                     else if ((uint32_t)(e >> kSkewPosBits) == fp) { cand = e & ((1ull << kSkewPosBits) - 1); ++n_match; }
                 }
-                if (n_match != 1 && (n_match > 1 || full)) {
+                // a full bucket may have spilled keys into the overflow list, and the one matching slot may then be a mere
+                // fingerprint collision: flag every item of a full bucket, so a failed verification goes to the exact walk
+                if (full || n_match > 1) {
                     S.qinfo[i] |= kQMulti;
                     if (n_match == 0) cand = 0; // any valid position: its verification fails and the flag sends the item to the exact walk
                 }
@@ -926,7 +929,8 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
 // lookup path never reads.
 // ------------------------------------------------------------------------------------
 template <uint32_t KW>
-__global__ __launch_bounds__(kBlock, 4) void validate_self_kernel(IndexView ix, unsigned long long *report) {
+__global__ __launch_bounds__(kBlock, 4) void validate_self_kernel(IndexView ix, unsigned long long *report, unsigned long long *dup_list,
+                                                                    uint64_t dup_cap) {
     fix_kw<KW>(ix);
     using SC = WaveScope; // every wavefront validates its own 128 positions (256 items), like k2u_wave_kernel
     __shared__ TileLdsT<SC::NT> SS[kBlock / 64];
@@ -989,7 +993,16 @@ __global__ __launch_bounds__(kBlock, 4) void validate_self_kernel(IndexView ix, 
                             dup = kw == fw || kw == kmer_rc(fw, k);
                         }
                     }
-                    if (dup) ++n_dup; else { ++n_fail; atomicMin(&report[3], (unsigned long long)p); }
+                    if (dup) {
+                        ++n_dup;
+                        if (dup_list && o == 0) { // listed once per k-mer: the position that is NOT the one the lookup answers with
+                            const unsigned long long slot = atomicAdd(&report[4], 1ull);
+                            if (slot < dup_cap) dup_list[slot] = p;
+                        }
+                    } else {
+                        ++n_fail;
+                        atomicMin(&report[3], (unsigned long long)p);
+                    }
                 }
             }
         }
@@ -1166,15 +1179,15 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
     return MZ_OK;
 }
 
-int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, hipStream_t stream) {
+int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, uint64_t *d_dup_list, uint64_t dup_cap, hipStream_t stream) {
     MZ_HIP_CHECK(hipSetDevice(d.device));
     uint64_t n_tiles = ((d.view.total_len + 64 * kQpt / 2 - 1) / (64 * kQpt / 2) + kBlock / 64 - 1) / (kBlock / 64); // four wave tiles per workgroup
     if (d.view.k == 31 && d.view.w == 15)
         hipLaunchKernelGGL(validate_self_kernel<kKW3115>, dim3(tile_grid(d, n_tiles, 16)), dim3(kBlock), 0, stream, d.view,
-                           (unsigned long long *)d_report);
+                           (unsigned long long *)d_report, (unsigned long long *)d_dup_list, dup_cap);
     else
         hipLaunchKernelGGL(validate_self_kernel<0>, dim3(tile_grid(d, n_tiles, 16)), dim3(kBlock), 0, stream, d.view,
-                           (unsigned long long *)d_report);
+                           (unsigned long long *)d_report, (unsigned long long *)d_dup_list, dup_cap);
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;
 }

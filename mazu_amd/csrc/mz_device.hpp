@@ -18,6 +18,15 @@ struct DeviceIndex {
     uint32_t n_cu = 256;
 };
 
+// restores the caller's current HIP device when an entry point that switched devices returns
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 int device_count();
 // copies every array of `h` into HBM of `device`
 int device_upload(const SSHashHost &h, int device, DeviceIndex **out);
@@ -31,8 +40,9 @@ int launch_k2u_compact(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, u
 int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
                      const uint64_t *d_kmer_offsets, uint64_t n_reads, int streaming, mz_k2upos *d_out,
                      mz_counts *d_counts, hipStream_t stream);
-// d_report: 4 x u64 {n_kmers, n_fail, n_duplicate, first_fail_pos}; caller initialises {0,0,0,~0}
-int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, hipStream_t stream);
+// d_report: 5 x u64 {n_kmers, n_fail, n_duplicate, first_fail_pos, n_listed}; caller initialises {0,0,0,~0,0}.
+// d_dup_list (may be null): receives up to dup_cap global positions of k-mers whose canonical word occurs earlier too
+int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, uint64_t *d_dup_list, uint64_t dup_cap, hipStream_t stream);
 int launch_extract_kmers(const DeviceIndex &d, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
                          uint64_t *d_fw, hipStream_t stream);
 
@@ -41,3 +51,6 @@ bool gpu_build_supported(const UnitigSet &us, uint32_t w);
 int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device);
 
 } // namespace mz
+
+// device of the replica the host-pointer entry points of `ix` use (placed on device 0 first if the index is not resident yet)
+int mz_internal_default_device(mz_sshash *ix, int *device);

@@ -656,8 +656,17 @@ static void scan_unitig(const uint64_t *useq, uint64_t s, uint64_t e, uint32_t k
     }
 }
 
+uint32_t skew_fp_bits_for_build() {
+    if (const char *e = std::getenv("MZ_TEST_SKEW_FP_BITS")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= (int)kSkewFpBits) return (uint32_t)v;
+    }
+    return kSkewFpBits;
+}
+
 void SkewTable::build(const uint64_t *words, const uint64_t *pos, uint64_t n, int n_threads) {
     n_keys = n;
+    fp_bits = skew_fp_bits_for_build();
     n_buckets = n ? (n + kSkewLoad - 1) / kSkewLoad : 0;
     buckets.assign(std::max<uint64_t>(n_buckets * kSkewSlots, 2), kSkewEmpty);
     ovf_word.clear();
@@ -668,11 +677,12 @@ void SkewTable::build(const uint64_t *words, const uint64_t *pos, uint64_t n, in
     {
         Occ *BY = by.data();
         const uint64_t nb = n_buckets;
+        const uint32_t fm = fp_mask();
         parallel_for(n_threads, n, [=](int, uint64_t b, uint64_t e) {
             for (uint64_t i = b; i < e; ++i) {
                 uint64_t hb;
                 uint32_t fp;
-                skew_home(words[i], nb, hb, fp);
+                skew_home(words[i], nb, fm, hb, fp);
                 BY[i] = Occ{hb, i};
             }
         });
@@ -685,7 +695,7 @@ void SkewTable::build(const uint64_t *words, const uint64_t *pos, uint64_t n, in
         const uint64_t rank = j - run_start, i = by[j].pos;
         uint64_t hb;
         uint32_t fp;
-        skew_home(words[i], n_buckets, hb, fp);
+        skew_home(words[i], n_buckets, fp_mask(), hb, fp);
         if (rank < kSkewSlots) B[hb * kSkewSlots + rank] = skew_slot(fp, pos[i]);
         else { ovf_word.push_back(words[i]); ovf_pos.push_back(pos[i]); }
     }
@@ -890,7 +900,7 @@ uint64_t SSHashHost::num_bits() const {
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '0', '9'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '1', '0'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>
@@ -902,9 +912,14 @@ static void putv(std::ofstream &f, const std::vector<T> &v) {
 template <class T>
 static bool get(std::ifstream &f, T &x) { return (bool)f.read((char *)&x, sizeof x); }
 template <class T>
-static bool getv(std::ifstream &f, std::vector<T> &v) {
+static bool getv(std::ifstream &f, std::vector<T> &v) { // the length is checked against what is left of the file before anything is allocated
     uint64_t n;
     if (!get(f, n)) return false;
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streampos end = f.tellg();
+    f.seekg(here);
+    if (here < 0 || end < here || n > (uint64_t)(end - here) / sizeof(T)) return false;
     v.resize(n);
     return (bool)f.read((char *)v.data(), n * sizeof(T));
 }
@@ -927,29 +942,90 @@ int SSHashHost::save(const std::string &path) const {
     put(f, hs);
     putv(f, us.useq); putv(f, us.starts); putv(f, us.bv_blocks); put_ef(f, us.accum_lens);
     put_mphf(f, mm); put(f, buckets.n); put(f, buckets.n_overflow); putv(f, buckets.blocks); putv(f, buckets.ovf); put_pv(f, pos);
-    if (has_skew) { put(f, skew.n_buckets); put(f, skew.n_keys); putv(f, skew.buckets); putv(f, skew.ovf_word); putv(f, skew.ovf_pos); }
+    if (has_skew) { put(f, skew.n_buckets); put(f, skew.n_keys); put(f, skew.fp_bits); putv(f, skew.buckets); putv(f, skew.ovf_word); putv(f, skew.ovf_pos); }
     return f ? MZ_OK : (set_error("short write to %s", path.c_str()), MZ_EIO);
+}
+
+// every size and offset the kernels rely on is checked here, so that a truncated, stale or damaged file is refused
+// instead of sending a kernel out of bounds; returns a description of the first inconsistency or nullptr
+static const char *check_loaded(const SSHashHost &h) {
+    const UnitigSet &us = h.us;
+    if (us.k == 0 || us.k > 31) return "k out of range";
+    if (h.w == 0 || h.w > us.k) return "w out of range";
+    if (us.n_unitigs == 0 || us.n_unitigs > 0xFFFFFFFFull || us.total_len == 0 || us.total_len >= (1ull << 36)) return "unitig set out of range";
+    if (us.useq.size() != (us.total_len + 31) / 32 + 2) return "packed sequence length";
+    if (us.starts.size() != us.n_unitigs + 1 || us.starts[0] != 0 || us.starts[us.n_unitigs] != us.total_len) return "unitig offsets";
+    for (uint64_t i = 0; i < us.n_unitigs; ++i)
+        if (us.starts[i + 1] <= us.starts[i] || us.starts[i + 1] - us.starts[i] > 0xFFFFFFFFull) return "unitig offsets not increasing";
+    if (us.bv_blocks.size() != ((us.total_len >> kBvBasesPerBlockLog2) + 1) * 8) return "boundary blocks";
+    if (us.accum_lens.n != us.n_unitigs + 1 || us.accum_lens.l == 0 || us.accum_lens.l > 32 || us.accum_lens.sel.size() != (us.accum_lens.n >> kEfSelLog2) + 2 ||
+        us.accum_lens.high.size() != us.accum_lens.n_high_bits / 64 + 4 || us.accum_lens.low.size() != (us.accum_lens.n * us.accum_lens.l + 63) / 64 + 2)
+        return "unitig offset Elias-Fano";
+    if (h.pos.width != kPosEntryBits || h.pos.w.size() != h.pos.n + 2 || h.pos.n == 0) return "entry array";
+    if (h.n_minimizers == 0 || h.buckets.n != h.n_minimizers + 1 || h.buckets.blocks.size() != (((h.buckets.n - 1) >> kBefShift) + 1) * 8) return "bucket offsets";
+    for (uint64_t j = 0; j < h.buckets.blocks.size(); j += 8) { // overflowed blocks point into the plain table
+        const uint64_t hdr = h.buckets.blocks[j];
+        if ((hdr >> 63) && (hdr & ((1ull << 40) - 1)) + kBefSpan + 1 > h.buckets.ovf.size()) return "bucket offset overflow table";
+    }
+    {
+        uint64_t a, b;
+        h.buckets.get_pair(h.n_minimizers - 1, a, b);
+        if (b != h.pos.n || a > b) return "bucket offsets do not end at the entry count";
+    }
+    if (h.mm.n_keys != h.n_minimizers) return "minimizer count";
+    if (h.mm.direct) {
+        if (2 * h.w > 32 || !h.mm.levels.empty() || h.mm.blocks.size() != (((1ull << (2 * h.w)) >> kMinRecKeysLog2) + 1) * kMinRecWords) return "minimizer records";
+        uint64_t run = 0;
+        for (uint64_t j = 0; j < h.mm.blocks.size(); j += kMinRecWords) {
+            const uint64_t *W = h.mm.blocks.data() + j;
+            if ((W[0] & kMinRecRankMask) != run) return "minimizer record ranks";
+            const uint32_t c = minrec_members(W);
+            run += c;
+            if (c && !(W[8] >> 63)) { // bucket starts of the record's members: the last one bounds them all
+                uint64_t a = 0, b = 0;
+                if (c > kBefSpan || !bef_block_pair(W + 8, c - 1, nullptr, a, b) || b > h.pos.n || a > b) return "minimizer record offsets";
+            }
+        }
+        if (run != h.n_minimizers) return "minimizer record ranks";
+    } else {
+        if (h.mm.blocks.size() % 8 != 0 || h.mm.levels.size() > kMphfMaxLevels) return "minimizer MPHF";
+        for (const MphfLevel &L : h.mm.levels)
+            if (L.n_blocks == 0 || L.block_off + L.n_blocks > h.mm.blocks.size() / 8) return "minimizer MPHF levels";
+    }
+    if (h.has_skew) {
+        const SkewTable &t = h.skew;
+        if (t.fp_bits < 1 || t.fp_bits > kSkewFpBits || t.buckets.size() != std::max<uint64_t>(t.n_buckets * kSkewSlots, 2) || t.ovf_word.size() != t.ovf_pos.size()) return "skew table";
+        const uint64_t last = us.total_len >= us.k ? us.total_len - us.k : 0, pmask = (1ull << kSkewPosBits) - 1;
+        for (uint64_t e : t.buckets)
+            if (e != kSkewEmpty && (e & pmask) > last) return "skew table position";
+        for (uint64_t p : t.ovf_pos)
+            if (p > last) return "skew overflow position";
+    }
+    return nullptr;
 }
 
 int SSHashHost::load(const std::string &path) {
     std::ifstream f(path, std::ios::binary);
     char magic[8];
     if (!f || !f.read(magic, 8) || std::memcmp(magic, kMagic, 8) != 0) {
-        set_error("%s: not a mazu_amd SSHash file", path.c_str());
+        set_error("%s: not a mazu_amd SSHash file (or one of another format version)", path.c_str());
         return MZ_EIO;
     }
     uint32_t hs = 0;
     bool ok = get(f, us.k) && get(f, w) && get(f, seed) && get(f, skew_param) && get(f, us.total_len) && get(f, us.n_unitigs) &&
               get(f, n_minimizers) && get(f, hs) && getv(f, us.useq) && getv(f, us.starts) && getv(f, us.bv_blocks) &&
-              get_ef(f, us.accum_lens) && get_mphf(f, mm) && get(f, buckets.n) && get(f, buckets.n_overflow) && getv(f, buckets.blocks) && getv(f, buckets.ovf) && get_pv(f, pos) && pos.width == kPosEntryBits;
+              get_ef(f, us.accum_lens) && get_mphf(f, mm) && get(f, buckets.n) && get(f, buckets.n_overflow) && getv(f, buckets.blocks) && getv(f, buckets.ovf) && get_pv(f, pos);
     has_skew = hs != 0;
-    if (ok && has_skew) ok = get(f, skew.n_buckets) && get(f, skew.n_keys) && getv(f, skew.buckets) && getv(f, skew.ovf_word) && getv(f, skew.ovf_pos) &&
-                             skew.buckets.size() == std::max<uint64_t>(skew.n_buckets * kSkewSlots, 2) && skew.ovf_word.size() == skew.ovf_pos.size();
-    if (ok) us.build_seqbv();
+    if (ok && has_skew) ok = get(f, skew.n_buckets) && get(f, skew.n_keys) && get(f, skew.fp_bits) && getv(f, skew.buckets) && getv(f, skew.ovf_word) && getv(f, skew.ovf_pos);
     if (!ok) {
         set_error("%s: truncated", path.c_str());
         return MZ_EIO;
     }
+    if (const char *what = check_loaded(*this)) {
+        set_error("%s: inconsistent index file (%s)", path.c_str(), what);
+        return MZ_EIO;
+    }
+    us.build_seqbv();
     return MZ_OK;
 }
 

@@ -96,8 +96,10 @@ private:
 struct SkewTable {
     std::vector<uint64_t> buckets, ovf_word, ovf_pos;
     uint64_t n_buckets = 0, n_keys = 0;
+    uint32_t fp_bits = kSkewFpBits; // fingerprint width of a slot
+    uint32_t fp_mask() const { return (uint32_t)((1ull << fp_bits) - 1); }
     void build(const uint64_t *words, const uint64_t *pos, uint64_t n, int n_threads);
-    SkewView view() const { return SkewView{buckets.data(), ovf_word.data(), ovf_pos.data(), n_buckets, (uint64_t)ovf_word.size(), n_keys}; }
+    SkewView view() const { return SkewView{buckets.data(), ovf_word.data(), ovf_pos.data(), n_buckets, (uint64_t)ovf_word.size(), n_keys, fp_mask(), 0}; }
     uint64_t num_bits() const { return 64 * (uint64_t)(buckets.size() + ovf_word.size() + ovf_pos.size()); }
 };
 
@@ -120,6 +122,10 @@ struct SSHashHost {
     int save(const std::string &path) const;
     int load(const std::string &path);
 };
+
+// fingerprint width the builders give a new skew table: kSkewFpBits, or MZ_TEST_SKEW_FP_BITS (1..kSkewFpBits; a knob for
+// tests that need fingerprint collisions to be common)
+uint32_t skew_fp_bits_for_build();
 
 void set_error(const char *fmt, ...);
 const char *last_error();

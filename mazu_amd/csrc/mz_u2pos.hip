@@ -215,7 +215,8 @@ int mz_u2pos_dense_new(const uint64_t *ctable, uint64_t n_occs, const uint64_t *
 }
 void mz_u2pos_free(mz_u2pos *u) {
     if (!u) return;
-    if (u->d_ctable) { (void)hipFree(u->d_ctable); (void)hipFree(u->d_offsets); }
+    DeviceGuard guard;
+    if (u->d_ctable) { (void)hipSetDevice(u->device); (void)hipFree(u->d_ctable); (void)hipFree(u->d_offsets); }
     delete u;
 }
 uint64_t mz_u2pos_n_unitig_occs(const mz_u2pos *u, uint64_t ui) { return ui < u->n_unitigs ? u->offsets[ui + 1] - u->offsets[ui] : 0; }
@@ -225,6 +226,7 @@ int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, ui
                             uint64_t out_cap, void *stream_) {
     if (!u || !d_offsets || (n && !d_recs)) { set_error("null argument"); return MZ_EINVAL; }
     hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard;
     int rc = ensure_u2pos_device(u, device_of(d_offsets));
     if (rc != MZ_OK) return rc;
     U2_HIP(hipSetDevice(u->device));
@@ -248,6 +250,7 @@ int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, ui
 
 int mz_u2pos_check_refs_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint32_t ref_id, uint64_t *d_report, void *stream_) {
     if (!u || !d_report || (n && !d_recs)) { set_error("null argument"); return MZ_EINVAL; }
+    DeviceGuard guard;
     int rc = ensure_u2pos_device(u, device_of(d_report));
     if (rc != MZ_OK) return rc;
     U2_HIP(hipSetDevice(u->device));
@@ -262,13 +265,15 @@ int mz_get_ref_pos_batch(mz_sshash *ix, mz_u2pos *u, const uint64_t *fw_words, u
                          uint64_t out_cap, uint64_t *n_out) {
     if (!ix || !u || !hit_offsets || !n_out || (n && !fw_words)) { set_error("null argument"); return MZ_EINVAL; }
     *n_out = 0;
-    int rc = mz_sshash_to_device(ix, 0);
+    DeviceGuard guard;
+    int device = 0; // the replica the handle's host-pointer entry points use; the handle is not retargeted
+    int rc = mz_internal_default_device(ix, &device);
     if (rc != MZ_OK) return rc;
     const uint32_t k = mz_sshash_k(ix);
     uint64_t *d_q = nullptr, *d_off = nullptr;
     mz_k2upos *d_r = nullptr;
     mz_mapped_ref_pos *d_o = nullptr;
-    U2_HIP(hipSetDevice(0));
+    U2_HIP(hipSetDevice(device));
     auto cleanup = [&] { if (d_q) (void)hipFree(d_q); if (d_off) (void)hipFree(d_off); if (d_r) (void)hipFree(d_r); if (d_o) (void)hipFree(d_o); };
     hipError_t e;
     if ((e = hipMalloc((void **)&d_q, std::max<uint64_t>(n, 1) * 8)) != hipSuccess || (e = hipMalloc((void **)&d_off, (n + 1) * 8)) != hipSuccess ||

@@ -1,8 +1,9 @@
 """Host-side mirror of mazu's index facade around the K2U path (reference src/index.rs,
 src/index/validate.rs, src/index/caching.rs, src/index/dense_unitig_table.rs): ModIndex.from_parts,
 get_ref_pos, validate_self, as_streaming.  The k2u step goes to the GPU through the K2U object
-it is given (mazu_amd.SSHash); occurrence projection stays on the host (numpy) -- it is the
-"next" row of SURVEY.md 8(f), not part of the accelerated path."""
+it is given (mazu_amd.SSHash).  Occurrence projection exists twice: a numpy restatement of
+project_onto_u_occ (the host mirror the tests compare against) and the device form of mz_u2pos.hip
+behind get_ref_pos_batch / validate_self_on_device / validate_fasta_on_device."""
 import numpy as np
 
 import ctypes as C
@@ -182,7 +183,7 @@ class ModIndex:  # src/index.rs:49-124
         on the device; returns the number of k-mers checked, raises where the reference would panic"""
         import torch
         assert self.refs.has_seq()
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", torch.cuda.current_device())  # the caller's GPU (one process per GPU: its LOCAL_RANK)
         report = torch.tensor([0, 0, -1], dtype=torch.int64, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         for r in range(self.refs.n_refs()):
@@ -319,7 +320,7 @@ def validate_fasta_on_device(index, path):
     assertion on the device; returns the number of k-mers checked."""
     import torch
     from .fasta import read_fasta
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", torch.cuda.current_device())  # the caller's GPU
     report = torch.tensor([0, 0, -1], dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     k = index.k()

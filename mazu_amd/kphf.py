@@ -187,6 +187,7 @@ class SSHash:  # sshash.rs:39-51
     def n_minimizer_occs(self): return lib.mz_sshash_n_minimizer_occs(self._h)
     def n_kmers_in_skew_index(self): return lib.mz_sshash_n_kmers_in_skew_index(self._h)
     def num_bits(self): return lib.mz_sshash_num_bits(self._h)
+    def minimizer_mphf_kind(self): return lib.mz_sshash_minimizer_mphf_kind(self._h)
     def device_bytes(self): return lib.mz_sshash_device_bytes(self._h)
     def to_device(self, device=0): check(lib.mz_sshash_to_device(self._h, device))
 
@@ -236,6 +237,15 @@ class SSHash:  # sshash.rs:39-51
         rep = _capi.ValidateReport()
         check(lib.mz_sshash_validate_self(self._h, C.byref(rep)))
         return {"n_kmers": rep.n_kmers, "n_fail": rep.n_fail, "n_duplicate": rep.n_duplicate, "first_fail_pos": rep.first_fail_pos}
+
+    def validate_self_duplicates(self, cap=4096):
+        """validate_self_report plus the (sorted) global positions of up to `cap` duplicated k-mers"""
+        rep = _capi.ValidateReport()
+        buf = np.zeros(cap, dtype=np.uint64)
+        n = C.c_uint64(0)
+        check(lib.mz_sshash_validate_self_duplicates(self._h, C.byref(rep), buf.ctypes.data, cap, C.byref(n)))
+        d = {"n_kmers": rep.n_kmers, "n_fail": rep.n_fail, "n_duplicate": rep.n_duplicate, "first_fail_pos": rep.first_fail_pos}
+        return d, np.sort(buf[: n.value])
 
     def validate_self(self):
         """K2U::validate_self (kphf/mod.rs:69-103): raises where the reference's asserts would fire."""

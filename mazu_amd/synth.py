@@ -19,12 +19,15 @@ import math
 import torch
 
 PRESETS = {
-    # name: n_unitigs, mean extra length, cap, fraction of bases planted, families
-    "s-tiny": dict(n_unitigs=300, mean_extra=400.0, cap=5000, plant_frac=0.08, n_families=8),
-    "s-yeast": dict(n_unitigs=6000, mean_extra=1985.0, cap=80000, plant_frac=0.08, n_families=64),
-    "s-txome": dict(n_unitigs=1_200_000, mean_extra=90.0, cap=20000, plant_frac=0.04, n_families=512),
-    "s-eighth": dict(n_unitigs=36145130 // 8, mean_extra=68.3, cap=33414 - 31, plant_frac=0.08, n_families=2048),
-    "s-human": dict(n_unitigs=36145130, mean_extra=68.3, cap=33414 - 31, plant_frac=0.08, n_families=16384),
+    # name: n_unitigs, mean extra length, cap, fraction of bases planted, families, exact total length (None = as drawn)
+    "s-tiny": dict(n_unitigs=300, mean_extra=400.0, cap=5000, plant_frac=0.08, n_families=8, total_len=None),
+    "s-yeast": dict(n_unitigs=6000, mean_extra=1985.0, cap=80000, plant_frac=0.08, n_families=64, total_len=None),
+    "s-txome": dict(n_unitigs=1_200_000, mean_extra=90.0, cap=20000, plant_frac=0.04, n_families=512, total_len=None),
+    "s-eighth": dict(n_unitigs=36145130 // 8, mean_extra=68.8, cap=33414 - 31, plant_frac=0.08, n_families=2048, total_len=3_589_802_592 // 8),
+    # cuttlefish GRCh38 k=31 (reference src/cuttlefish.rs:25-44): 36 145 130 unitigs, 3 589 802 592 bp, longest 33 414
+    "s-human": dict(n_unitigs=36145130, mean_extra=68.8, cap=33414 - 31, plant_frac=0.08, n_families=16384, total_len=3_589_802_592),
+    # pan-genome scale (an assumption: no in-tree figure exists): 120 M unitigs, 9 Gbp
+    "s-pan": dict(n_unitigs=120_000_000, mean_extra=44.5, cap=33414 - 31, plant_frac=0.08, n_families=32768, total_len=9_000_000_000),
 }
 
 
@@ -34,8 +37,27 @@ def _gen(device, seed):
     return g
 
 
+def _fit_total(lens, k, cap, target):
+    """nudge unitig lengths (every one stays in [k, k + cap]) so that they sum to `target` exactly"""
+    n = lens.numel()
+    delta = int(target) - int(lens.sum())
+    while delta != 0:
+        step = 1 if delta > 0 else -1
+        room = (lens < k + cap) if step > 0 else (lens > k)
+        idx = torch.nonzero(room).flatten()
+        if idx.numel() == 0:
+            raise ValueError("cannot reach the requested total length")
+        take = min(abs(delta), idx.numel())
+        # spread over the eligible unitigs at a fixed stride, so the adjustment is not piled on the first ones
+        pick = idx[(torch.arange(take, device=lens.device) * (idx.numel() // take))]
+        lens[pick] += step
+        delta -= step * take
+    return lens
+
+
 def make_unitig_set(preset, k=31, seed=0x6D617A75, device="cpu", total_len=None):
-    """returns dict(words int64[nw+2], starts int64[n+1], total_len, n_unitigs, k) on `device`."""
+    """returns dict(words int64[nw+2], starts int64[n+1], total_len, n_unitigs, k) on `device`.
+    total_len (or the preset's) makes the sum of the unitig lengths exact."""
     p = dict(PRESETS[preset]) if isinstance(preset, str) else dict(preset)
     dev = torch.device(device)
     g = _gen(dev, seed)
@@ -43,33 +65,89 @@ def make_unitig_set(preset, k=31, seed=0x6D617A75, device="cpu", total_len=None)
     u = torch.rand(n, generator=g, device=dev, dtype=torch.float64).clamp_(1e-12, 1.0)
     extra = (-torch.log(u) * p["mean_extra"]).floor_().clamp_(max=float(p["cap"])).to(torch.int64)
     lens = extra + k
+    del u, extra
+    target = total_len if total_len is not None else p.get("total_len")
+    if target is not None:
+        lens = _fit_total(lens, k, int(p["cap"]), target)
     starts = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(lens, 0, out=starts[1:])
-    if total_len is not None:  # stretch / trim the last unitig so that the sum is exact
-        delta = int(total_len) - int(starts[-1])
-        if int(lens[-1]) + delta < k:
-            raise ValueError("cannot reach requested total_len")
-        starts[-1] += delta
+    del lens
     L = int(starts[-1])
     nw = (L + 31) // 32
     words = torch.randint(-(2**63), 2**63 - 1, (nw + 2,), generator=g, device=dev, dtype=torch.int64)
     # planted 16-mers at 32-bit aligned half-word slots
     n_fam = p["n_families"]
     n_plants = int(p["plant_frac"] * L / 16)
-    if n_fam > 0 and n_plants > 0:
+    if n_fam > 0 and n_plants > 0 and nw > 2:
         fam_words = torch.randint(0, 2**32, (n_fam,), generator=g, device=dev, dtype=torch.int64)
-        # low half of distinct words only: two plants are always separated by >= 16 random bases,
+        # low half of distinct words only: two plants are always separated by >= 16 other bases,
         # so no 31-mer is made of planted bases alone
-        w_idx = torch.randperm(nw, generator=g, device=dev)[:n_plants]
+        w_idx = torch.randperm(nw - 1, generator=g, device=dev)[:n_plants] + 1
         fam = torch.randint(0, n_fam, (w_idx.numel(),), generator=g, device=dev)
-        lo_mask = torch.tensor(0xFFFFFFFF, dtype=torch.int64, device=dev)
-        words[w_idx] = (words[w_idx] & ~lo_mask) | fam_words[fam]
+        # Two copies of one family would otherwise share 31-mers with probability 4^-15 per pair and offset.  The 8 bases
+        # on either side of a plant are therefore a tag that is unique among the copies of its family (a bijection of the
+        # copy's rank): a 31-mer that holds a whole plant also holds one whole tag, so copies never repeat a 31-mer.
+        order = torch.argsort(fam, stable=True)
+        counts = torch.bincount(fam, minlength=n_fam)
+        if int(counts.max()) > 65536:
+            raise ValueError("more than 65536 copies of one planted family")
+        first = torch.cumsum(counts, 0) - counts
+        rank = torch.empty_like(fam)
+        rank[order] = torch.arange(fam.numel(), device=dev) - first[fam[order]]
+        tag_r = (rank * 40503 + fam * 0x9E37) & 0xFFFF
+        tag_l = (rank * 25173 + fam * 0x7F4B + 0x1234) & 0xFFFF
+        del order, counts, first, rank
+        words[w_idx] = (words[w_idx] & -(1 << 48)) | fam_words[fam] | (tag_r << 32)     # plant + the 8 bases after it
+        words[w_idx - 1] = (words[w_idx - 1] & ((1 << 48) - 1)) | (tag_l << 48)         # the 8 bases before it
+        del w_idx, fam, tag_r, tag_l
     # zero the slack bits and the two pad words
     words[nw:] = 0
     if L & 31:
         keep = (1 << (2 * (L & 31))) - 1
         words[nw - 1] &= keep
     return dict(words=words, starts=starts, total_len=L, n_unitigs=n, k=k, preset=preset if isinstance(preset, str) else "custom")
+
+
+def mutate_positions(us, positions):
+    """substitute the base at each global position (code + 1 mod 4) in place: used to break up the handful of duplicate
+    31-mers that a random background of billions of bases holds by the birthday bound"""
+    words = us["words"]
+    for p in sorted(set(int(x) for x in positions)):
+        wi, sh = p >> 5, (p & 31) * 2
+        v = int(words[wi]) & (2**64 - 1)
+        old = (v >> sh) & 3
+        v ^= (old ^ ((old + 1) & 3)) << sh
+        words[wi] = v - 2**64 if v >= 2**63 else v
+    return us
+
+
+def build_index_unique(us, w, skew_param, seed=0, device=0, on_device=True, max_rounds=4, log=None):
+    """build the SSHash of a synthetic unitig set and make its canonical k-mers unique: duplicates reported by the device
+    validate_self (a few at GRCh38 scale: the birthday bound of random sequence) are broken up by substituting one base
+    in the middle of the later copy, and the index is rebuilt.  Returns (index, report, rounds)."""
+    from . import kphf
+    import numpy as np
+    k = us["k"]
+    for rnd in range(max_rounds):
+        words_h = us["words"].cpu().numpy().view(np.uint64)
+        starts_h = us["starts"].cpu().numpy().view(np.uint64)
+        uset = kphf.UnitigSet.from_packed(words_h, us["total_len"], starts_h, k)
+        ix = (kphf.SSHash.from_unitig_set_on_device(uset, w, skew_param, seed, device=device) if on_device
+              else kphf.SSHash.from_unitig_set(uset, w, skew_param, seed))
+        del uset
+        ix.to_device(device)
+        rep, dups = ix.validate_self_duplicates()
+        if log:
+            log(f"validate_self round {rnd}: {rep}")
+        if rep["n_fail"] != 0:
+            raise AssertionError(f"validate_self failed: {rep}")
+        if rep["n_duplicate"] == 0:
+            return ix, rep, rnd
+        if len(dups) < min(rep["n_duplicate"], 1):
+            raise AssertionError("duplicates reported but not listed")
+        mutate_positions(us, [int(p) + k // 2 for p in dups])
+        del ix
+    raise AssertionError("duplicate k-mers remain after %d rounds" % max_rounds)
 
 
 def sample_positive_positions(starts, k, n, generator):

@@ -16,20 +16,38 @@ K2UPOS_DTYPE = np.dtype([("unitig_id", "<u4"), ("pos", "<u4"), ("unitig_len", "<
 NO_SKEW = 2**64 - 1
 
 
-def build_lib(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+def _host_has_v3():
+    """AVX2 / BMI2 / FMA / LZCNT / MOVBE on this host (the x86-64-v3 level liboracle_v3.so is compiled for)"""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    have = set(line.split(":", 1)[1].split())
+                    return {"avx2", "bmi1", "bmi2", "fma", "abm", "movbe", "f16c"} <= have
+    except OSError:
+        pass
+    return False
+
+
+BUILD_FLAGS = None  # compiler flags of the library that was loaded (reported beside the CPU baseline)
+
+
+def build_lib(force=False, name="liboracle.so"):
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "sshash_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, name], stdout=subprocess.DEVNULL)
     return so
 
 
 def lib():
-    global _LIB
+    global _LIB, BUILD_FLAGS
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        name = "liboracle_v3.so" if _host_has_v3() and os.environ.get("MZ_ORACLE_PORTABLE") is None else "liboracle.so"
+        so = os.path.join(_HERE, name)
         if not os.path.exists(so):
-            so = build_lib()
+            so = build_lib(name=name)
+        BUILD_FLAGS = "gcc -O3 -fopenmp" + (" -march=x86-64-v3" if name.endswith("_v3.so") else "")
         L = C.CDLL(so)
         u64, u32, p = C.c_uint64, C.c_uint32, C.c_void_p
         L.orc_build.restype = p

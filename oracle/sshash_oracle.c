@@ -297,11 +297,39 @@ static void mphf_build(mphf *m, const uint64_t *keys_in, uint64_t n, double gamm
                 if (old & bit) __atomic_fetch_or(&col.w[p >> 6], bit, __ATOMIC_RELAXED);
             }
         }
-        for (uint64_t j = 0; j < occ.n_words; ++j) occ.w[j] &= ~col.w[j];
+#pragma omp parallel for schedule(static)
+        for (int64_t j = 0; j < (int64_t)occ.n_words; ++j) occ.w[j] &= ~col.w[j];
+        /* keys whose bit did not survive go on to the next level, in their old order (chunks compacted in parallel) */
         uint64_t nr = 0;
-        for (uint64_t i = 0; i < remaining; ++i) {
-            uint64_t p = mphf_level_pos(keys[i], m->n_levels, size);
-            if (!bv_get(&occ, p)) keys[nr++] = keys[i];
+        {
+            int nt = 1;
+#ifdef _OPENMP
+            nt = omp_get_max_threads();
+#endif
+            uint64_t *cnt = (uint64_t *)calloc((size_t)nt + 1, 8);
+            uint64_t *next = (uint64_t *)malloc((remaining ? remaining : 1) * 8);
+            unsigned lvl = m->n_levels;
+            uint64_t per = (remaining + (uint64_t)nt - 1) / (uint64_t)nt;
+#pragma omp parallel for schedule(static, 1)
+            for (int t = 0; t < nt; ++t) {
+                uint64_t b = per * (uint64_t)t, e = b + per < remaining ? b + per : remaining, c = 0;
+                for (uint64_t i = b; i < e; ++i) {
+                    uint64_t p = mphf_level_pos(keys[i], lvl, size);
+                    c += !((occ.w[p >> 6] >> (p & 63)) & 1);
+                }
+                cnt[t + 1] = c;
+            }
+            for (int t = 0; t < nt; ++t) cnt[t + 1] += cnt[t];
+#pragma omp parallel for schedule(static, 1)
+            for (int t = 0; t < nt; ++t) {
+                uint64_t b = per * (uint64_t)t, e = b + per < remaining ? b + per : remaining, o = cnt[t];
+                for (uint64_t i = b; i < e; ++i) {
+                    uint64_t p = mphf_level_pos(keys[i], lvl, size);
+                    if (!((occ.w[p >> 6] >> (p & 63)) & 1)) next[o++] = keys[i];
+                }
+            }
+            nr = cnt[nt];
+            free(cnt); free(keys); keys = next;
         }
         bv_free(&col);
         bv_enable_rank_select(&occ);
@@ -438,20 +466,36 @@ orc_index *orc_build(const uint64_t *useq_words, uint64_t total_len, const uint6
         uint64_t cap = 1024, n = 0, tcap = 0;
         mm_occ *occ = (mm_occ *)malloc(cap * sizeof *occ);
         uint64_t *t_w = NULL, *t_p = NULL; uint8_t *t_f = NULL; /* per-unitig minimizer of every k-mer */
+        uint64_t *h_f = NULL, *h_r = NULL;                      /* hash of every w-mer of the unitig, forward strand / reverse complement */
+        const uint64_t wmask = w == 32 ? ~0ull : ((1ull << (2 * w)) - 1);
         for (uint64_t ui = u_lo; ui < u_hi; ++ui) {
             uint64_t s = starts[ui], e = starts[ui + 1];
             if (e - s < k) continue;
-            uint64_t nk = e - s - k + 1;
+            uint64_t nk = e - s - k + 1, nwm = e - s - w + 1;
             if (nk > tcap) {
                 tcap = nk * 2;
                 t_w = (uint64_t *)realloc(t_w, tcap * 8); t_p = (uint64_t *)realloc(t_p, tcap * 8); t_f = (uint8_t *)realloc(t_f, tcap);
+                h_f = (uint64_t *)realloc(h_f, (tcap + k) * 8); h_r = (uint64_t *)realloc(h_r, (tcap + k) * 8);
+            }
+            /* the sliding form of canonical_minimizer() (iter_canonical_minimizers, call site sshash.rs:104-134): every
+             * w-mer is hashed once per strand; the k-mer at j then takes the leftmost minimum over the k-w+1 w-mers of its
+             * canonical strand -- the same (word, offset) canonical_minimizer() returns for that k-mer */
+            for (uint64_t j = 0; j < nwm; ++j) {
+                uint64_t m = seq_get_kmer(us->useq, s + j, w);
+                h_f[j] = orc_hash64(m, seed);
+                h_r[j] = orc_hash64(kmer_rc(m, w), seed);
             }
             for (uint64_t j = 0; j < nk; ++j) {
-                uint64_t fw = seq_get_kmer(us->useq, s + j, k);
-                uint64_t mw; unsigned o; int is_fw;
-                canonical_minimizer(fw, k, w, seed, &mw, &o, &is_fw);
-                t_w[j] = mw; t_f[j] = (uint8_t)is_fw;
-                t_p[j] = is_fw ? s + j + o : s + j + (k - o - w);
+                uint64_t fw = seq_get_kmer(us->useq, s + j, k), rc = kmer_rc(fw, k);
+                int is_fw = fw <= rc;
+                uint64_t g = is_fw ? fw : rc, best_h = 0;
+                unsigned o_best = 0;
+                for (unsigned o = 0; o + w <= k; ++o) { /* offset o inside g*; on the reverse strand it is forward w-mer j + (k-w-o) */
+                    uint64_t h = is_fw ? h_f[j + o] : h_r[j + (k - w - o)];
+                    if (o == 0 || h < best_h) { best_h = h; o_best = o; }
+                }
+                t_w[j] = (g >> (2 * o_best)) & wmask; t_f[j] = (uint8_t)is_fw;
+                t_p[j] = is_fw ? s + j + o_best : s + j + (k - o_best - w);
             }
             for (int pass = 0; pass < 2; ++pass) {
                 int have_prev = 0; uint64_t prev_w = 0, prev_p = 0;
@@ -465,6 +509,7 @@ orc_index *orc_build(const uint64_t *useq_words, uint64_t total_len, const uint6
                 }
             }
         }
+        free(h_f); free(h_r);
         free(t_w); free(t_p); free(t_f);
         part[c] = occ; part_n[c] = n;
     }
@@ -489,13 +534,34 @@ orc_index *orc_build(const uint64_t *useq_words, uint64_t total_len, const uint6
         unsigned wb = 2 * w, B = wb < 10 ? wb : 10, shift = wb - B;
         uint64_t nbk = 1ull << B;
         uint64_t *bstart = (uint64_t *)calloc(nbk + 1, 8);
-        for (uint64_t i = 0; i < n_occ; ++i) bstart[(occs[i].word >> shift) + 1]++;
-        for (uint64_t b = 0; b < nbk; ++b) bstart[b + 1] += bstart[b];
-        uint64_t *cur = (uint64_t *)malloc(nbk * 8);
-        memcpy(cur, bstart, nbk * 8);
+        int nt = 1;
+#ifdef _OPENMP
+        nt = omp_get_max_threads();
+#endif
+        /* counting sort on the top bits, chunks of the input handled in parallel and laid down in chunk order (stable) */
+        uint64_t *hist = (uint64_t *)calloc((size_t)nt * nbk, 8);
+        uint64_t per = (n_occ + (uint64_t)nt - 1) / (uint64_t)nt;
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < nt; ++t) {
+            uint64_t b = per * (uint64_t)t, e = b + per < n_occ ? b + per : n_occ;
+            for (uint64_t i = b; i < e; ++i) hist[(uint64_t)t * nbk + (occs[i].word >> shift)]++;
+        }
+        {
+            uint64_t acc = 0;
+            for (uint64_t b = 0; b < nbk; ++b) {
+                bstart[b] = acc;
+                for (int t = 0; t < nt; ++t) { uint64_t c = hist[(uint64_t)t * nbk + b]; hist[(uint64_t)t * nbk + b] = acc; acc += c; }
+            }
+            bstart[nbk] = acc;
+        }
         mm_occ *tmp = (mm_occ *)malloc(n_occ * sizeof *tmp);
-        for (uint64_t i = 0; i < n_occ; ++i) tmp[cur[occs[i].word >> shift]++] = occs[i];
-        free(cur); free(occs); occs = tmp;
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < nt; ++t) {
+            uint64_t b = per * (uint64_t)t, e = b + per < n_occ ? b + per : n_occ;
+            uint64_t *cur = hist + (uint64_t)t * nbk;
+            for (uint64_t i = b; i < e; ++i) tmp[cur[occs[i].word >> shift]++] = occs[i];
+        }
+        free(hist); free(occs); occs = tmp;
 #pragma omp parallel for schedule(dynamic, 1)
         for (int64_t b = 0; b < (int64_t)nbk; ++b)
             qsort(occs + bstart[b], bstart[b + 1] - bstart[b], sizeof *occs, cmp_mm_occ);
@@ -594,9 +660,12 @@ orc_index *orc_build(const uint64_t *useq_words, uint64_t total_len, const uint6
         for (uint64_t i = 0; i < un; ++i) { km_set[i] = tup[i].word; if (tup[i].pos > smax) smax = tup[i].pos; }
         mphf_build(&ix->skew_mphf, km_set, un, 1.7);
         iv_init(&ix->skew_pos, un, bit_len(smax));
-        for (uint64_t i = 0; i < un; ++i) {
-            uint64_t h = 0; mphf_try_hash(&ix->skew_mphf, km_set[i], &h);
-            iv_set(&ix->skew_pos, h, tup[i].pos);
+        {
+            uint64_t *hs = (uint64_t *)malloc((un ? un : 1) * 8);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)un; ++i) { uint64_t h = 0; mphf_try_hash(&ix->skew_mphf, km_set[i], &h); hs[i] = h; }
+            for (uint64_t i = 0; i < un; ++i) iv_set(&ix->skew_pos, hs[i], tup[i].pos);
+            free(hs);
         }
         ix->has_skew = 1;
         free(km_set); free(tup);
@@ -604,7 +673,9 @@ orc_index *orc_build(const uint64_t *useq_words, uint64_t total_len, const uint6
     /* 7. finish, sshash.rs:310-329: EF-encode prefix sums, bit-pack pos */
     ef_build(&ix->occs_prefix_sum, psum, n_mm + 1, psum[n_mm]);
     iv_init(&ix->pos, n_occ, bit_len(max_pos));
-    for (uint64_t i = 0; i < n_occ; ++i) iv_set(&ix->pos, i, pos[i]);
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < (int64_t)((n_occ + 63) / 64); ++g) /* 64 elements of any width end on a word boundary: groups never share a word */
+        for (uint64_t i = (uint64_t)g * 64; i < n_occ && i < ((uint64_t)g + 1) * 64; ++i) iv_set(&ix->pos, i, pos[i]);
     free(pos); free(psum); free(n_by_h); free(ranges); free(mm_cnt); free(mm_set); free(occs);
 
     /* brute-force dictionary: every valid k-mer position, keyed by canonical word */

@@ -63,3 +63,35 @@ def test_sharded_counts_allreduce_world2(tmp_path):
     assert counts.tolist() == [n_hit, len(q) - n_hit, 0]
     got = np.concatenate([np.load(tmp_path / "out0.npy"), np.load(tmp_path / "out1.npy")])
     assert got.tobytes() == want.tobytes()  # shards stay in order: concatenation == unsharded result
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`bench.py --gpus 2` outside torchrun starts two ranks (fresh processes), they meet in one process group, the
+    tallies are all-reduced, and the parent's stdout is rank 0's single JSON line"""
+    import json
+    r = _run_bench({"MZ_DIST_BACKEND": "gloo"}, "--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]  # gloo itself chats on stdout ("[Gloo] Rank 0 is connected ...")
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["counts"] == [3, 30, 0] and res["max_over_ranks"] == 2.0
+
+
+def test_bench_gpus_n_fails_loudly_without_n_gpus():
+    """with the RCCL backend and fewer than N visible GPUs the launcher must exit non-zero with a clear message,
+    never fall back to one rank silently"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("box has 2+ GPUs")
+    r = _run_bench({"MZ_DIST_BACKEND": "nccl"}, "--gpus", "2", "--launch-check")
+    assert r.returncode != 0
+    assert "GPU(s) visible" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())

@@ -1,0 +1,281 @@
+"""GPU tests (-m gpu) at the sizes BASELINE.json's configurations name, plus the failure side of the validator.
+
+  * s-eighth: the headline kernel combination -- k2u_wave_kernel<31,15> x direct minimizer records x negative filter x
+    skew table on a GPU-built index -- byte-identical to the oracle on a 50/50 NEG-U mix and on NEG-1 negatives
+  * s-txome reads through mz_sshash_k2u_reads_device (.as_streaming() request) == the oracle's StreamingK2U walk
+  * s-human and s-pan at full size: K2U::validate_self on the device, every sampled positive equal to the answer
+    computed from the plain unitig offsets (an independent ground truth that needs no index), negatives miss,
+    reverse-complement symmetry
+  * a corrupted index must FAIL validate_self, at the position that was corrupted
+"""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import helpers as H
+import mazu_amd as M
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CF_YEAST = os.path.join(H.GOLDEN, "cf", "yeast_chr7", "yeast_chr7")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    assert M.lib.mz_device_count() >= 1, "GPU tests need a visible HIP device (no CPU fallback exists)"
+
+
+def _host_arrays(us):
+    return us["words"].cpu().numpy().view(np.uint64), us["starts"].cpu().numpy().view(np.uint64)
+
+
+def _k2u_device(ix, q):
+    import torch
+    out = torch.zeros(q.numel() * 2, dtype=torch.int64, device=q.device)
+    cnt = torch.zeros(3, dtype=torch.int64, device=q.device)
+    ix.k2u_batch_device(q, out, cnt, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out, cnt.cpu().tolist()
+
+
+def test_s_eighth_headline_kernel_matches_oracle():
+    """BASELINE configs[3] at 1/8 scale (452 Mbp, 4.5 M unitigs): same kernel specialisation and index form as the headline"""
+    import torch
+    from mazu_amd import synth
+    us = synth.make_unitig_set("s-eighth", device="cuda")
+    assert us["total_len"] == 3_589_802_592 // 8
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True)
+    assert ix.minimizer_mphf_kind() == 1 and ix.n_kmers_in_skew_index() > 0  # direct minimizer records + a populated skew table
+    assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and rep["n_kmers"] == ix.n_kmers()
+    q = synth.make_query_mix(ix, us, 2_000_000, seed=11, device="cuda")                         # 50/50 NEG-U
+    q1 = synth.make_query_mix(ix, us, 400_000, seed=12, device="cuda", neg_kind="sub1")        # 200 k positives + 200 k NEG-1
+    qq = torch.cat([q, q1])
+    out, (n_hit, n_miss, _) = _k2u_device(ix, qq)
+    words, starts = _host_arrays(us)
+    orc = O.OracleSSHash(words, us["total_len"], starts, 31, 15, 32, with_dict=False)
+    want, o_hit = orc.k2u_batch(qq.cpu().numpy().view(np.uint64), n_threads=M.lib.mz_host_threads())
+    got = out.cpu().numpy().view(M.K2UPOS_DTYPE)
+    assert got.tobytes() == want.tobytes()
+    assert (n_hit, n_miss) == (o_hit, qq.numel() - o_hit)
+    assert abs(n_hit - 1_200_000) <= 8  # positives hit; NEG-U / NEG-1 negatives miss (up to accidental members)
+
+
+def test_s_txome_reads_match_oracle_streaming_walk():
+    """BASELINE configs[2] shape: 150-bp reads over a 145 Mbp, 1.2 M-unitig set, requested as .as_streaming();
+    every window must equal the oracle's StreamingK2U walk (index/caching.rs:65-103, bin/kphf/main.rs:299-312)"""
+    import torch
+    from mazu_amd import synth
+    us = synth.make_unitig_set("s-txome", device="cuda")
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True)
+    assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0
+    n_reads, read_len = 20_000, 150
+    bases, ro = synth.make_reads(us, n_reads, read_len, seed=2000, device="cuda")
+    ko = synth.kmer_offsets(ro, 31)
+    out = torch.zeros(int(ko[-1]) * 2, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ix.k2u_reads_device(bases, ro, ko, out, cnt, streaming=True, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    words, starts = _host_arrays(us)
+    orc = O.OracleSSHash(words, us["total_len"], starts, 31, 15, 32, with_dict=False)
+    want, ko_h, oc = orc.k2u_reads(bases.cpu().numpy(), ro.cpu().numpy().astype(np.uint64), streaming=True)
+    cold, _, _ = orc.k2u_reads(bases.cpu().numpy(), ro.cpu().numpy().astype(np.uint64), streaming=False)
+    assert want.tobytes() == cold.tobytes()  # unique k-mers: the streaming walk equals independent lookups
+    got = out.cpu().numpy().view(M.K2UPOS_DTYPE)
+    assert got.tobytes() == want.tobytes() and cnt.cpu().tolist() == oc.tolist()
+    assert 0.3 < oc[0] / (n_reads * 120) < 0.99  # junction windows and substituted reads miss, the rest hit
+
+
+def _full_size_properties(preset, n_q):
+    """validate_self on the device + sampled positives against the answer derived from the plain offsets"""
+    import torch
+    from mazu_amd import synth
+    us = synth.make_unitig_set(preset, device="cuda")
+    assert us["total_len"] == synth.PRESETS[preset]["total_len"] and us["n_unitigs"] == synth.PRESETS[preset]["n_unitigs"]
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True)
+    assert ix.minimizer_mphf_kind() == 1
+    assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and rep["n_kmers"] == ix.n_kmers()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    starts = us["starts"]
+    pos = synth.sample_positive_positions(starts, 31, n_q, g)
+    flip = torch.randint(0, 2, (n_q,), generator=g, device=dev, dtype=torch.uint8)
+    q = torch.empty(n_q, dtype=torch.int64, device=dev)
+    ix.extract_kmers_device(pos, flip, q)
+    torch.cuda.synchronize()
+    out, (n_hit, n_miss, _) = _k2u_device(ix, q)
+    rec = out.view(torch.int32).view(-1, 4).to(torch.int64) & 0xFFFFFFFF  # unitig_id, pos, unitig_len, match
+    uid = torch.searchsorted(starts, pos, right=True) - 1
+    assert n_hit == n_q and n_miss == 0
+    assert torch.equal(rec[:, 0], uid)
+    assert torch.equal(rec[:, 1], pos - starts[uid])
+    assert torch.equal(rec[:, 2], starts[uid + 1] - starts[uid])
+    assert torch.equal(rec[:, 3], 1 + flip.to(torch.int64))  # forward word -> Identity, reverse complement -> Twin
+    # NEG-U negatives miss (accidental members: ~n_kmers / 4^31 each), and k2u(rc(q)) mirrors k2u(q)
+    neg = torch.randint(0, 2 ** 62, (n_q,), generator=g, device=dev, dtype=torch.int64)
+    _, (h2, m2, _) = _k2u_device(ix, neg)
+    assert h2 <= 2 and h2 + m2 == n_q
+    q_rc = torch.empty_like(q)
+    ix.extract_kmers_device(pos, 1 - flip, q_rc)
+    torch.cuda.synchronize()
+    out_rc, _ = _k2u_device(ix, q_rc)
+    rec_rc = out_rc.view(torch.int32).view(-1, 4).to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(rec_rc[:, :3], rec[:, :3]) and torch.equal(rec_rc[:, 3], 3 - rec[:, 3])
+    return ix
+
+
+def test_s_human_full_size_properties():
+    """BASELINE configs[3] on one GPU's replica: 36 145 130 unitigs, 3 589 802 592 bp (reference src/cuttlefish.rs:25-44)"""
+    _full_size_properties("s-human", 4_000_000)
+
+
+def test_s_pan_full_size_properties():
+    """BASELINE configs[4]: 120 M unitigs, 9 Gbp, one GPU's replica (positions beyond 2^33, ids beyond 2^26)"""
+    ix = _full_size_properties("s-pan", 4_000_000)
+    assert ix.sum_unitigs_len() == 9_000_000_000 and ix.n_unitigs() == 120_000_000
+
+
+# ---------------------------------------------------------------- the validator must be able to fail
+class FlatIndexFile:
+    """offsets of the arrays inside the flat index file written by mz_sshash_save (length-prefixed little-endian vectors)"""
+
+    def __init__(self, data):
+        self.d = bytearray(data)
+        assert bytes(self.d[:8]) == b"MZSSH010"
+        o = 8
+        self.k, self.w = struct.unpack_from("<II", self.d, o); o += 8
+        self.seed, self.skew_param, self.total_len, self.n_unitigs, self.n_minimizers = struct.unpack_from("<5Q", self.d, o); o += 40
+        (self.has_skew,) = struct.unpack_from("<I", self.d, o); o += 4
+        self.vec = {}
+
+        def vec(name, o, item=8):
+            (n,) = struct.unpack_from("<Q", self.d, o)
+            self.vec[name] = (o + 8, n)
+            return o + 8 + n * item
+        o = vec("useq", o); o = vec("starts", o); o = vec("bv_blocks", o)
+        o += 8 * 3 + 4  # accum_lens: u, n, n_high_bits, l
+        o = vec("ef_high", o); o = vec("ef_sel", o); o = vec("ef_low", o)
+        o += 8 + 4      # minimizer mphf: n_keys, direct
+        o = vec("mm_blocks", o); o = vec("mm_levels", o, 24)
+        o += 16         # bucket offsets: n, n_overflow
+        o = vec("bef_blocks", o); o = vec("bef_ovf", o)
+        o += 8 + 4      # pos: n, width
+        o = vec("pos", o)
+        if self.has_skew:
+            o += 8 + 8 + 4  # n_buckets, n_keys, fp_bits
+            o = vec("skew_buckets", o); o = vec("skew_ovf_word", o); o = vec("skew_ovf_pos", o)
+        assert o == len(self.d), (o, len(self.d))
+
+    def get(self, name, i):
+        off, n = self.vec[name]
+        assert i < n
+        return struct.unpack_from("<Q", self.d, off + 8 * i)[0]
+
+    def put(self, name, i, v):
+        off, n = self.vec[name]
+        assert i < n
+        struct.pack_into("<Q", self.d, off + 8 * i, v)
+
+    def n(self, name):
+        return self.vec[name][1]
+
+
+@pytest.fixture(scope="module")
+def yeast_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("flat")
+    us = M.UnitigSet.from_cf_prefix(CF_YEAST)
+    no_skew = M.SSHash.from_unitig_set_no_skew_index(us, 15)
+    skew = M.SSHash.from_unitig_set(us, 15, 8)
+    no_skew.validate_self()
+    skew.validate_self()
+    no_skew.save(d / "noskew.mz")
+    skew.save(d / "skew.mz")
+    return d
+
+
+def _load_corrupted(f, path):
+    with open(path, "wb") as fh:
+        fh.write(bytes(f.d))
+    return M.SSHash.load(path)
+
+
+def test_validate_self_fails_on_a_corrupted_pos_entry(yeast_files):
+    f = FlatIndexFile(open(yeast_files / "noskew.mz", "rb").read())
+    k, w = f.k, f.w
+    e = f.n("pos") // 2
+    ent = f.get("pos", e)
+    mm_pos = ent >> 17
+    f.put("pos", e, ((mm_pos + 5) << 17) | (ent & 0x1FFFF))  # same flanks and strand class, wrong position
+    ix = _load_corrupted(f, yeast_files / "bad_pos.mz")
+    rep = ix.validate_self_report()
+    assert 2 <= rep["n_fail"] <= 2 * (k - w + 1) and rep["n_kmers"] == ix.n_kmers()
+    assert mm_pos - (k - w) <= rep["first_fail_pos"] <= mm_pos  # a k-mer whose minimizer is that occurrence
+    with pytest.raises(AssertionError):
+        ix.validate_self()  # kphf/mod.rs:69-103 would panic here
+
+
+def test_validate_self_fails_on_a_moved_unitig_boundary(yeast_files):
+    f = FlatIndexFile(open(yeast_files / "noskew.mz", "rb").read())
+    i = f.n_unitigs // 2
+    old = f.get("starts", i)
+    f.put("starts", i, old + 1)  # unitig i-1 gains the first base of unitig i: its new last k-mer straddles the true junction
+    ix = _load_corrupted(f, yeast_files / "bad_boundary.mz")
+    rep = ix.validate_self_report()
+    assert rep["n_fail"] == 2 and rep["first_fail_pos"] == old + 1 - f.k  # that one k-mer, both orientations
+    with pytest.raises(AssertionError):
+        ix.validate_self()
+
+
+def test_validate_self_fails_on_a_corrupted_skew_slot(yeast_files):
+    f = FlatIndexFile(open(yeast_files / "skew.mz", "rb").read())
+    assert f.has_skew and f.n("skew_buckets") > 16
+    s = next(j for j in range(f.n("skew_buckets") // 2, f.n("skew_buckets")) if f.get("skew_buckets", j) != 2 ** 64 - 1)
+    slot = f.get("skew_buckets", s)
+    p = slot & ((1 << 36) - 1)
+    f.put("skew_buckets", s, (slot & ~((1 << 36) - 1)) | (p + 7))  # same fingerprint, wrong k-mer position
+    ix = _load_corrupted(f, yeast_files / "bad_skew.mz")
+    rep = ix.validate_self_report()
+    assert rep["n_fail"] == 2 and rep["first_fail_pos"] == p
+    with pytest.raises(AssertionError):
+        ix.validate_self()
+
+
+def test_skew_fingerprint_collision_with_an_overflowed_key(monkeypatch, tmp_path):
+    """4-bit fingerprints and every k-mer in the skew index: full buckets spill keys into the overflow list, and for many
+    of those keys exactly one slot of the full home bucket shares the fingerprint.  The staged kernel must then fall back
+    to the exact walk (which searches the overflow list) instead of reporting a miss."""
+    monkeypatch.setenv("MZ_TEST_SKEW_FP_BITS", "4")
+    k, seqs = H.load_cf_seqs(CF_YEAST)
+    words, total, starts = H.pack_seqs(seqs)
+    for on_device in (False, True):
+        us = M.UnitigSet.from_packed(words, total, starts, k)
+        ix = M.SSHash.from_unitig_set_on_device(us, 13, 0) if on_device else M.SSHash.from_unitig_set(us, 13, 0)
+        assert ix.n_kmers_in_skew_index() == ix.n_kmers()
+        ix.save(tmp_path / "fp4.mz")
+        f = FlatIndexFile(open(tmp_path / "fp4.mz", "rb").read())
+        assert f.n("skew_ovf_word") > 100  # keys beyond the 16th of their bucket
+        rep = ix.validate_self_report()
+        assert rep["n_fail"] == 0 and rep["n_kmers"] == ix.n_kmers()
+    monkeypatch.delenv("MZ_TEST_SKEW_FP_BITS")
+    orc = O.OracleSSHash(words, total, starts, k, 13, 0)
+    q = H.query_mix(words, starts, k, 200_000, seed=5)
+    got, _ = ix.k2u_batch(q)
+    want, _ = orc.k2u_batch(q, n_threads=8)
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("w,skew", [(13, 32), (9, 4), (15, 16)])
+def test_gpu_build_with_implied_strand_class(monkeypatch, tmp_path, w, skew):
+    """occurrence keys one bit short (pan-genome lengths with w = 15) leave the strand class out of the sort key and derive
+    it from the sequence; forced here on a small set: the arrays must still be the host builder's"""
+    us = M.UnitigSet.from_cf_prefix(CF_YEAST)
+    host = M.SSHash.from_unitig_set(us, w, skew)
+    monkeypatch.setenv("MZ_TEST_GPU_BUILD_IMPLIED_CLASS", "1")
+    dev = M.SSHash.from_unitig_set_on_device(us, w, skew)
+    host.save(tmp_path / "h.mz")
+    dev.save(tmp_path / "d.mz")
+    assert open(tmp_path / "h.mz", "rb").read() == open(tmp_path / "d.mz", "rb").read()
+    dev.validate_self()
