@@ -435,11 +435,17 @@ int UnitigSet::finish() {
     return MZ_OK;
 }
 
-// interleave the packed sequence and the boundary blocks into 128-byte records (IndexView::seqbv)
+// interleave the packed sequence and the boundary blocks into 128-byte records (IndexView::seqbv).  The boundary bits of a
+// record are cut out of the boundary bit vector (bv_blocks, the reference's `bv`: a bit at the last base of every unitig,
+// unitig_set.rs:90-96); the header words come from the offsets.
 void UnitigSet::build_seqbv() {
     const uint64_t nr = (total_len + kSeqRecStride - 1) / kSeqRecStride + 1; // + a tail record: never probed by a valid position
     seqbv.assign(nr * kSeqRecWords, 0);
-    const uint64_t nw = useq.size();
+    const uint64_t nw = useq.size(), n_bvb = bv_blocks.size() / 8;
+    auto bv_word = [&](uint64_t wi) -> uint64_t { // 64 boundary bits starting at base 64 * wi
+        const uint64_t blk = wi >> 2;
+        return blk < n_bvb ? bv_blocks[blk * 8 + 4 + (wi & 3)] : 0;
+    };
     uint64_t uid = 0; // unitig holding the first base of the current record
     for (uint64_t r = 0; r < nr; ++r) {
         uint64_t *W = seqbv.data() + r * kSeqRecWords;
@@ -453,17 +459,14 @@ void UnitigSet::build_seqbv() {
             continue;
         }
         const uint64_t lastb = std::min<uint64_t>(first + kBvBasesPerBlock - 1, total_len - 1);
+        for (uint32_t j = 0; j < 4; ++j) { // bits [first + 64 j, first + 64 j + 64): first is a multiple of 32
+            const uint64_t b = first + 64ull * j, wi = b >> 6;
+            const uint32_t sh = (uint32_t)(b & 63);
+            W[12 + j] = sh ? (bv_word(wi) >> sh) | (bv_word(wi + 1) << (64 - sh)) : bv_word(wi);
+        }
         while (starts[uid + 1] <= first) ++uid;
         uint64_t ul = uid; // -> the unitig holding the last base of the record
-        while (starts[ul + 1] <= lastb) { // every unitig that ends inside the record: bit at its last base (unitig_set.rs:90-93)
-            const uint64_t o = starts[ul + 1] - 1 - first;
-            W[12 + (o >> 6)] |= 1ull << (o & 63);
-            ++ul;
-        }
-        if (starts[ul + 1] - 1 == lastb) { // its own last base is the last base of the record
-            const uint64_t o = lastb - first;
-            W[12 + (o >> 6)] |= 1ull << (o & 63);
-        }
+        while (starts[ul + 1] <= lastb) ++ul;
         W[8] = uid;
         W[9] = starts[uid];
         W[10] = starts[ul + 1];

@@ -28,6 +28,10 @@ def need_gpu():
     assert M.lib.mz_device_count() >= 1, "GPU tests need a visible HIP device (no CPU fallback exists)"
 
 
+def _log(msg):
+    print(msg, flush=True)  # long steps at full size keep the log moving
+
+
 def _host_arrays(us):
     return us["words"].cpu().numpy().view(np.uint64), us["starts"].cpu().numpy().view(np.uint64)
 
@@ -47,7 +51,7 @@ def test_s_eighth_headline_kernel_matches_oracle():
     from mazu_amd import synth
     us = synth.make_unitig_set("s-eighth", device="cuda")
     assert us["total_len"] == 3_589_802_592 // 8
-    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True)
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
     assert ix.minimizer_mphf_kind() == 1 and ix.n_kmers_in_skew_index() > 0  # direct minimizer records + a populated skew table
     assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and rep["n_kmers"] == ix.n_kmers()
     q = synth.make_query_mix(ix, us, 2_000_000, seed=11, device="cuda")                         # 50/50 NEG-U
@@ -69,7 +73,7 @@ def test_s_txome_reads_match_oracle_streaming_walk():
     import torch
     from mazu_amd import synth
     us = synth.make_unitig_set("s-txome", device="cuda")
-    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True)
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
     assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0
     n_reads, read_len = 20_000, 150
     bases, ro = synth.make_reads(us, n_reads, read_len, seed=2000, device="cuda")
@@ -94,7 +98,7 @@ def _full_size_properties(preset, n_q):
     from mazu_amd import synth
     us = synth.make_unitig_set(preset, device="cuda")
     assert us["total_len"] == synth.PRESETS[preset]["total_len"] and us["n_unitigs"] == synth.PRESETS[preset]["n_unitigs"]
-    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True)
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
     assert ix.minimizer_mphf_kind() == 1
     assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and rep["n_kmers"] == ix.n_kmers()
     dev = torch.device("cuda")
@@ -217,28 +221,55 @@ def test_validate_self_fails_on_a_corrupted_pos_entry(yeast_files):
         ix.validate_self()  # kphf/mod.rs:69-103 would panic here
 
 
-def test_validate_self_fails_on_a_moved_unitig_boundary(yeast_files):
+def test_validate_self_fails_on_a_cleared_boundary_bit(yeast_files):
+    """the lookup locates unitigs through the boundary bit vector (bv.rank, unitig_set.rs:185-187), the validator walks the
+    unitigs through their offsets: a cleared bit merges two unitigs for the lookup only"""
     f = FlatIndexFile(open(yeast_files / "noskew.mz", "rb").read())
     i = f.n_unitigs // 2
-    old = f.get("starts", i)
-    f.put("starts", i, old + 1)  # unitig i-1 gains the first base of unitig i: its new last k-mer straddles the true junction
+    b = f.get("starts", i) - 1  # last base of unitig i-1
+    wi = (b >> 8) * 8 + 4 + ((b & 255) >> 6)
+    word = f.get("bv_blocks", wi)
+    assert (word >> (b & 63)) & 1
+    f.put("bv_blocks", wi, word & ~(1 << (b & 63)))
     ix = _load_corrupted(f, yeast_files / "bad_boundary.mz")
     rep = ix.validate_self_report()
-    assert rep["n_fail"] == 2 and rep["first_fail_pos"] == old + 1 - f.k  # that one k-mer, both orientations
+    assert rep["n_fail"] > 0 and rep["n_kmers"] == ix.n_kmers()
+    assert b - 256 <= rep["first_fail_pos"] <= b  # a k-mer of a sequence record that holds the cleared bit
     with pytest.raises(AssertionError):
         ix.validate_self()
 
 
-def test_validate_self_fails_on_a_corrupted_skew_slot(yeast_files):
+def test_validate_self_fails_on_a_substituted_base(yeast_files):
+    f = FlatIndexFile(open(yeast_files / "noskew.mz", "rb").read())
+    x = f.total_len // 3
+    word = f.get("useq", x >> 5)
+    f.put("useq", x >> 5, word ^ (1 << (2 * (x & 31))))
+    ix = _load_corrupted(f, yeast_files / "bad_base.mz")
+    rep = ix.validate_self_report()
+    assert 2 <= rep["n_fail"] <= 2 * f.k and x - f.k + 1 <= rep["first_fail_pos"] <= x  # k-mers that cover the base
+    with pytest.raises(AssertionError):
+        ix.validate_self()
+
+
+def test_validate_self_fails_on_corrupted_skew_slots(yeast_files):
+    """the skew table also holds the neighbours of every heavy occurrence, which are looked up through their own light
+    buckets; only k-mers whose OWN minimizer is heavy go through it.  Every slot gets a wrong position (same fingerprint):
+    exactly those k-mers must fail, the others must not."""
     f = FlatIndexFile(open(yeast_files / "skew.mz", "rb").read())
     assert f.has_skew and f.n("skew_buckets") > 16
-    s = next(j for j in range(f.n("skew_buckets") // 2, f.n("skew_buckets")) if f.get("skew_buckets", j) != 2 ** 64 - 1)
-    slot = f.get("skew_buckets", s)
-    p = slot & ((1 << 36) - 1)
-    f.put("skew_buckets", s, (slot & ~((1 << 36) - 1)) | (p + 7))  # same fingerprint, wrong k-mer position
+    off, n = f.vec["skew_buckets"]
+    slots = np.frombuffer(bytes(f.d[off:off + 8 * n]), dtype=np.uint64).copy()
+    used = slots != np.uint64(2 ** 64 - 1)
+    pos = slots & np.uint64((1 << 36) - 1)
+    flip = used & ((pos ^ np.uint64(1)) <= np.uint64(f.total_len - f.k))
+    slots[flip] ^= np.uint64(1)
+    f.d[off:off + 8 * n] = slots.tobytes()
+    good = M.SSHash.load(yeast_files / "skew.mz")
     ix = _load_corrupted(f, yeast_files / "bad_skew.mz")
     rep = ix.validate_self_report()
-    assert rep["n_fail"] == 2 and rep["first_fail_pos"] == p
+    assert 0 < rep["n_fail"] <= 2 * int(used.sum()) and rep["n_kmers"] == ix.n_kmers()
+    fw = H.kmer_words_at(good.as_ref().useq_words(), [rep["first_fail_pos"]], f.k)
+    assert good.k2u_batch(fw)[0]["match"][0] == 1 and ix.k2u_batch(fw)[0]["match"][0] == 0
     with pytest.raises(AssertionError):
         ix.validate_self()
 
