@@ -214,6 +214,18 @@ uint64_t mz_u2pos_num_total_occs(const mz_u2pos *u);             /* :34-36 */
  * MappedRefPos records of query i at [d_offsets[i], d_offsets[i+1]); records beyond out_cap are not written. */
 int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets,
                             mz_mapped_ref_pos *d_out, uint64_t out_cap, void *stream);
+/* place the table in the HBM of `device` now (otherwise done on first use) and prepare that GPU for the entry point below */
+int mz_u2pos_to_device(mz_u2pos *u, int device);
+/* mz_u2pos_project_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results; the partial sums of its scan live
+ * in a fixed array inside the library (128 KiB per GPU, held until the process ends) instead of stream-ordered scratch, and
+ * it calls no allocating routine.  Limits: n <= mz_u2pos_noalloc_max_queries() (2^24; MZ_EINVAL beyond), the table must
+ * already be resident on the GPU that owns d_offsets (mz_u2pos_to_device; MZ_EINVAL otherwise).  Every call on one GPU uses
+ * that GPU's one array: calls that overlap in time on the same GPU (different streams or threads) race and must be
+ * serialised by the caller. */
+int mz_u2pos_project_device_noalloc(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets,
+                                    mz_mapped_ref_pos *d_out, uint64_t out_cap, void *stream);
+uint64_t mz_u2pos_noalloc_max_queries(void);
 /* the assertion of Validate::validate_self (index/validate.rs:24-52) for the k-mers 0..n of reference ref_id whose K2UPos
  * records are d_recs: d_report[3] = {k-mers checked, failures, first failing position}, accumulated (init {0,0,~0}) */
 int mz_u2pos_check_refs_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint32_t ref_id, uint64_t *d_report,

@@ -95,6 +95,9 @@ def _load():
         "mz_u2pos_n_unitig_occs": (u64, [p, u64]),
         "mz_u2pos_num_total_occs": (u64, [p]),
         "mz_u2pos_project_device": (i, [p, u32, p, u64, p, p, u64, p]),
+        "mz_u2pos_to_device": (i, [p, i]),
+        "mz_u2pos_project_device_noalloc": (i, [p, u32, p, u64, p, p, u64, p]),
+        "mz_u2pos_noalloc_max_queries": (u64, []),
         "mz_u2pos_check_refs_device": (i, [p, u32, p, u64, u32, p, p]),
         "mz_get_ref_pos_batch": (i, [p, p, p, u64, p, p, u64, p]),
         "mz_streaming_new": (i, [p, p]),

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -31,6 +32,8 @@ constexpr int kB = 256, kItems = 4, kTileN = kB * kItems;
             return MZ_EHIP;                                                                \
         }                                                                                  \
     } while (0)
+
+unsigned grid_of(uint64_t n, unsigned cap = 256 * 16) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kB - 1) / kB, cap)); }
 
 // UnitigOcc::decode_pf1 (index.rs:334-346) + project_onto_u_occ (index.rs:184-216)
 __device__ __forceinline__ mz_mapped_ref_pos project(const mz_k2upos &r, uint64_t enc, uint32_t k, uint64_t query) {
@@ -173,7 +176,44 @@ __global__ __launch_bounds__(kB) void check_refs_kernel(const mz_k2upos *__restr
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&report[0], (unsigned long long)n);
 }
 
-unsigned grid_of(uint64_t n, unsigned cap = 256 * 16) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kB - 1) / kB, cap)); }
+
+// ---- scratch of the entry point that allocates nothing (mz_u2pos_project_device_noalloc) ----------------------------
+// The scan of the per-query counts needs one partial sum per tile of kTileN queries plus the grand total.  The existing
+// entry point takes them from the stream-ordered allocator; callers that may not allocate (code under graph capture, tight
+// serving loops) get them from this file-scope array instead.  Every GPU the library runs on holds its own copy of the
+// array, at its own address, until the process ends: 128 KiB + 16 bytes.
+constexpr uint64_t kNoAllocMaxQueries = 1ull << 24;                       // 16 Mi queries per call
+constexpr uint64_t kNoAllocMaxTiles = kNoAllocMaxQueries / kTileN;       // 16384 tiles
+static __device__ __align__(256) uint64_t scratch[kNoAllocMaxTiles + 2];
+constexpr int kMaxDevices = 64;
+uint64_t *g_scratch_ptr[kMaxDevices] = {}; // device address of `scratch` on each GPU, resolved by mz_u2pos_to_device
+std::mutex g_scratch_mu;
+
+// device address of this GPU's copy of `scratch`; `device` must be the current device
+int resolve_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) { set_error("device %d beyond the %d devices the no-allocation path tracks", device, kMaxDevices); return MZ_EINVAL; }
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (g_scratch_ptr[device]) return MZ_OK;
+    uint64_t *p = nullptr;
+    U2_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+    if (!p) { set_error("hipGetSymbolAddress returned a null address for the scratch array"); return MZ_EHIP; }
+    g_scratch_ptr[device] = p;
+    return MZ_OK;
+}
+
+__global__ void zero_word_kernel(uint64_t *p) { *p = 0; }
+
+// count -> exclusive scan -> fill on `stream`, tile sums in d_tiles (n_tiles + 2 words); shared by both entry points
+void launch_project(const mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets, mz_mapped_ref_pos *d_out, uint64_t out_cap,
+                    uint64_t *d_tiles, hipStream_t stream) {
+    const uint64_t n_tiles = (n + kTileN - 1) / kTileN;
+    hipLaunchKernelGGL(count_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->n_unitigs, d_offsets);
+    hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)n_tiles), dim3(kB), 0, stream, d_offsets, n, d_tiles);
+    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(kB), 0, stream, d_tiles, n_tiles, d_tiles + n_tiles);
+    hipLaunchKernelGGL(scan_apply, dim3((unsigned)n_tiles), dim3(kB), 0, stream, d_offsets, n, d_tiles, d_tiles + n_tiles);
+    if (d_out && out_cap)
+        hipLaunchKernelGGL(fill_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->d_ctable, d_offsets, k, d_out, out_cap);
+}
 
 int ensure_u2pos_device(mz_u2pos *u, int device) {
     if (u->d_ctable && u->device == device) return MZ_OK;
@@ -236,15 +276,43 @@ int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, ui
     if (n == 0) {
         U2_HIP(hipMemsetAsync(d_offsets, 0, 8, stream));
     } else {
-        hipLaunchKernelGGL(count_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->n_unitigs, d_offsets);
-        hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)n_tiles), dim3(kB), 0, stream, d_offsets, n, d_tiles);
-        hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(kB), 0, stream, d_tiles, n_tiles, d_tiles + n_tiles);
-        hipLaunchKernelGGL(scan_apply, dim3((unsigned)n_tiles), dim3(kB), 0, stream, d_offsets, n, d_tiles, d_tiles + n_tiles);
-        if (d_out && out_cap)
-            hipLaunchKernelGGL(fill_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->d_ctable, d_offsets, k, d_out, out_cap);
+        launch_project(u, k, d_recs, n, d_offsets, d_out, out_cap, d_tiles, stream);
     }
     U2_HIP(hipGetLastError());
     U2_HIP(hipFreeAsync(d_tiles, stream));
+    return MZ_OK;
+}
+
+int mz_u2pos_to_device(mz_u2pos *u, int device) {
+    if (!u) { set_error("null argument"); return MZ_EINVAL; }
+    DeviceGuard guard;
+    int rc = ensure_u2pos_device(u, device); // makes `device` current
+    if (rc != MZ_OK) return rc;
+    return resolve_scratch(device);
+}
+
+uint64_t mz_u2pos_noalloc_max_queries(void) { return kNoAllocMaxQueries; }
+
+int mz_u2pos_project_device_noalloc(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets, mz_mapped_ref_pos *d_out,
+                                    uint64_t out_cap, void *stream_) {
+    if (!u || !d_offsets || (n && !d_recs)) { set_error("null argument"); return MZ_EINVAL; }
+    if (n > kNoAllocMaxQueries) {
+        set_error("mz_u2pos_project_device_noalloc: %llu queries exceed the %llu its fixed scratch array covers; split the batch or use mz_u2pos_project_device",
+                  (unsigned long long)n, (unsigned long long)kNoAllocMaxQueries);
+        return MZ_EINVAL;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int device = device_of(d_offsets);
+    uint64_t *d_tiles = device >= 0 && device < kMaxDevices ? g_scratch_ptr[device] : nullptr;
+    if (!u->d_ctable || u->device != device || !d_tiles) {
+        set_error("mz_u2pos_project_device_noalloc: the table is not resident on device %d; call mz_u2pos_to_device(u, %d) once beforehand", device, device);
+        return MZ_EINVAL;
+    }
+    DeviceGuard guard;
+    U2_HIP(hipSetDevice(device));
+    if (n == 0) hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(1), 0, stream, d_offsets); // a kernel, not a memset node: safe under graph capture
+    else launch_project(u, k, d_recs, n, d_offsets, d_out, out_cap, d_tiles, stream);
+    U2_HIP(hipGetLastError());
     return MZ_OK;
 }
 
