@@ -76,6 +76,7 @@ def _load():
         "mz_sshash_n_kmers_in_skew_index": (u64, [p]),
         "mz_sshash_num_bits": (u64, [p]),
         "mz_sshash_minimizer_mphf_kind": (u32, [p]),
+        "mz_sshash_has_minimizer_lines": (u32, [p]),
         "mz_sshash_device_bytes": (u64, [p]),
         "mz_sshash_to_device": (i, [p, i]),
         "mz_sshash_k2u": (i, [p, u64, u32, p]),

@@ -265,6 +265,20 @@ __global__ __launch_bounds__(kB) void pos_entries_kernel(const uint64_t *__restr
     }
 }
 
+// minimizer lines (FrontTable::build of the host): one lane per line
+__global__ __launch_bounds__(kB) void front_lines_kernel(const uint64_t *__restrict__ minrec, uint32_t g, uint64_t n_lines, const uint64_t *__restrict__ psum,
+                                                         const uint64_t *__restrict__ entries, uint64_t skew_param, uint64_t *__restrict__ lines) {
+    uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t line = (uint64_t)blockIdx.x * kB + threadIdx.x; line < n_lines; line += stride) {
+        uint64_t bucket0;
+        const uint32_t members = front_line_members(minrec, g, line, bucket0);
+        uint64_t out[kFrontSlots];
+        front_build_line(g, members, bucket0, psum, entries, skew_param, out);
+#pragma unroll
+        for (uint32_t q = 0; q < kFrontSlots; ++q) lines[line * kFrontSlots + q] = out[q];
+    }
+}
+
 // ---- skew index ----
 // tuples around every occurrence of a heavy minimizer (sshash.rs:231-262): one lane per (occurrence, offset)
 template <bool STORE>
@@ -512,11 +526,25 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         hipLaunchKernelGGL(pos_entries_kernel, dim3(grid_of(n_words)), dim3(kB), 0, 0, d_keys, n_occ, P, h.pos.width, n_words, d_packed);
         hipLaunchKernelGGL(record_filters_kernel, dim3(grid_of(n_mm)), dim3(kB), 0, 0, d_minrec, d_mm, n_mm, d_psum, d_packed, skew_param);
         if (int rc = download(h.pos.w, d_packed, n_words)) return rc;
-        buf.release(d_packed);
         if (int rc = download(h.mm.blocks, d_minrec, n_rec * kMinRecWords)) return rc;
+        // minimizer lines from the finished records, bucket starts and entries
+        const int fg = FrontTable::choose_g(w, n_occ, true);
+        h.front.present = fg >= 0;
+        h.front.lines.clear();
+        if (fg >= 0) {
+            h.front.g = (uint32_t)fg;
+            const uint64_t n_lines = 1ull << (2 * w - fg);
+            uint64_t *d_lines = nullptr;
+            BG_HIP(buf.alloc(&d_lines, n_lines * kFrontSlots));
+            hipLaunchKernelGGL(front_lines_kernel, dim3(grid_of(n_lines)), dim3(kB), 0, 0, d_minrec, (uint32_t)fg, n_lines, d_psum, d_packed, skew_param, d_lines);
+            BG_HIP(hipGetLastError());
+            if (int rc = download(h.front.lines, d_lines, n_lines * kFrontSlots)) return rc;
+            buf.release(d_lines);
+        }
+        buf.release(d_packed);
         buf.release(d_minrec);
     }
-    phase("G3 offsets + pos entries");
+    phase("G3 offsets + entries + lines");
 
     // ---- G4: skew index
     if (skew_param != ~0ull) {

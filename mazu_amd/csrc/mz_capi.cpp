@@ -213,6 +213,7 @@ uint64_t mz_sshash_n_minimizer_occs(const mz_sshash *ix) { return ix->host.pos.n
 uint64_t mz_sshash_n_kmers_in_skew_index(const mz_sshash *ix) { return ix->host.has_skew ? ix->host.skew.n_keys : 0; }
 uint64_t mz_sshash_num_bits(const mz_sshash *ix) { return ix->host.num_bits(); }
 uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix) { return ix->host.mm.direct ? 1u : 0u; }
+uint32_t mz_sshash_has_minimizer_lines(const mz_sshash *ix) { return ix->host.front.present ? 1u : 0u; }
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix) { return ix->dev ? ix->dev->bytes : 0; } /* per replica */
 
 int mz_sshash_to_device(mz_sshash *ix, int device) {

@@ -359,6 +359,29 @@ MZ_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 #endif
 }
 
+// ---- minimizer lines ("front table") ------------------------------------------------------------------------------
+// For w-mers with 2w <= 32 the bucket entries of 2^g consecutive keys (g <= 4) live in ONE 128-byte line of 16 slots,
+// addressed directly by key >> g: a query learns membership, its bucket's entries and their flank fingerprints from a
+// single gather, where the reference probes an MPHF, two Elias-Fano offsets and then the position array
+// (sshash.rs:478-495).  Slot (64 bits):
+//   bits 0..1   kind: 0 = bucket entry, 1 = the key's bucket is heavy (answered by the skew index, sshash.rs:486-490),
+//               2 = the key's bucket did not fit the line (payload: its range in the entry array), 3 = empty slot
+//   bits 2..10  key & (2^g - 1) (9-bit field)
+//   bits 11..26 kind 0: flank16 of the occurrence in the orientation of the canonical k-mer; kind 2: bucket size (saturated)
+//   bit  27     kind 0: strand class of the occurrence
+//   bits 28..63 kind 0: minimizer position; kind 2: first entry of the bucket in the entry array
+// Slots are in key order, the entries of a key in bucket order.  Every member key owns at least one slot (2^g <= 16), so
+// a key with no slot is not a minimizer of the set.  Which buckets go inline is decided per line by front_build_line().
+constexpr uint32_t kFrontSlots = 16, kFrontMaxG = 4, kFrontKindBits = 2, kFrontKeyShift = 2, kFrontKeyBits = 9, kFrontFlankShift = 11,
+                   kFrontClsShift = 27, kFrontPosShift = 28;
+constexpr uint32_t kFrontEntry = 0, kFrontHeavy = 1, kFrontSpill = 2, kFrontEmptyKind = 3;
+constexpr uint64_t kFrontEmpty = ~0ull;
+constexpr uint32_t kFrontKeyMask = ((1u << kFrontKeyBits) - 1) << kFrontKeyShift;
+struct FrontView {
+    const uint64_t *lines; // n_lines * 16 slots; nullptr: the index has no minimizer lines
+    uint64_t n_lines;
+    uint32_t g, pad;
+};
 struct IndexView {
     uint32_t k, w;
     uint64_t seed;
@@ -373,6 +396,7 @@ struct IndexView {
     uint32_t pos_width;
     uint32_t has_skew;
     SkewView skew;             // canonical k-mer of a heavy bucket -> global k-mer position
+    FrontView front;           // minimizer lines: membership + inline bucket entries in one gather (optional)
     const uint64_t *starts;    // plain unitig starts (n_unitigs+1); used by validate_self only
 };
 
@@ -432,6 +456,78 @@ MZ_HD uint32_t flank_revcomp(uint32_t f) {
 #endif
     return x ^ 0xFFFFu;
 }
+// ---- minimizer lines: construction (layout at FrontView) -----------------------------------------------------------
+MZ_HD uint64_t front_entry_slot(uint64_t pos, uint32_t cls, uint32_t flank_canon, uint32_t keylow) {
+    return (pos << kFrontPosShift) | ((uint64_t)cls << kFrontClsShift) | ((uint64_t)flank_canon << kFrontFlankShift) | ((uint64_t)keylow << kFrontKeyShift) | kFrontEntry;
+}
+MZ_HD uint64_t front_marker_slot(uint32_t kind, uint32_t keylow, uint64_t first, uint64_t count) {
+    const uint64_t c = count < 0xFFFFull ? count : 0xFFFFull;
+    return (first << kFrontPosShift) | (c << kFrontFlankShift) | ((uint64_t)keylow << kFrontKeyShift) | kind;
+}
+// Packs one line.  member_bits: bit j set when key (line << g) + j is a minimizer; bucket0: bucket id of the first member
+// (bucket ids are ranks, so the members' buckets are bucket0, bucket0+1, ...); psum: bucket starts; entries: the entry
+// array (`pos` layout).  Light buckets are taken inline in order of increasing size (ties: key order) while every bucket
+// left out still keeps one slot for its marker.
+MZ_HD void front_build_line(uint32_t g, uint32_t member_bits, uint64_t bucket0, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param,
+                            uint64_t *out) {
+    uint32_t keylow[kFrontSlots], size_c[kFrontSlots];
+    uint64_t first[kFrontSlots], size[kFrontSlots];
+    bool inl[kFrontSlots];
+    uint32_t m = 0;
+    for (uint32_t j = 0; j < (1u << g); ++j)
+        if ((member_bits >> j) & 1) {
+            keylow[m] = j;
+            first[m] = psum[bucket0 + m];
+            size[m] = psum[bucket0 + m + 1] - first[m];
+            size_c[m] = size[m] > skew_param || size[m] > kFrontSlots ? 0xFFFFFFFFu : (uint32_t)size[m]; // heavy or hopeless: never inline
+            inl[m] = false;
+            ++m;
+        }
+    uint32_t used = m; // one slot per member to begin with
+    for (;;) {         // repeatedly take the smallest bucket not yet inline (ties: lowest key)
+        uint32_t best = kFrontSlots;
+        for (uint32_t a = 0; a < m; ++a)
+            if (!inl[a] && size_c[a] != 0xFFFFFFFFu && (best == kFrontSlots || size_c[a] < size_c[best])) best = a;
+        if (best == kFrontSlots || used - 1 + size_c[best] > kFrontSlots) break;
+        inl[best] = true;
+        used += size_c[best] - 1;
+    }
+    uint32_t o = 0;
+    for (uint32_t a = 0; a < m; ++a) {
+        if (inl[a]) {
+            for (uint64_t e = 0; e < size[a]; ++e) {
+                const uint64_t ent = entries[first[a] + e];
+                const uint32_t cls = (uint32_t)(ent >> 16) & 1u, fl = (uint32_t)(ent & 0xFFFFu);
+                out[o++] = front_entry_slot(ent >> 17, cls, cls ? flank_revcomp(fl) : fl, keylow[a]);
+            }
+        } else {
+            out[o++] = front_marker_slot(size[a] > skew_param ? kFrontHeavy : kFrontSpill, keylow[a], first[a], size[a]);
+        }
+    }
+    for (; o < kFrontSlots; ++o) out[o] = kFrontEmpty;
+}
+// the 2^g membership bits of line `line` from the minimizer records, and the bucket id of its first member
+MZ_HD uint32_t front_line_members(const uint64_t *minrec, uint32_t g, uint64_t line, uint64_t &bucket0) {
+    const uint64_t key0 = line << g;
+    const uint64_t *W = minrec + (key0 >> kMinRecKeysLog2) * kMinRecWords;
+    const uint32_t in_rec = (uint32_t)(key0 & ((1u << kMinRecKeysLog2) - 1)), j = in_rec >> 6, bi = in_rec & 63;
+    const uint64_t hdr = W[2 * j], wv = W[2 * j + 1];
+    bucket0 = (hdr & kMinRecRankMask) + (hdr >> 40) + popc64(wv & ~(~0ull << bi));
+    return (uint32_t)((wv >> bi) & ((1ull << (1u << g)) - 1)); // 2^g <= 16 keys never straddle a bitmap word
+}
+// g for a key universe of 2^(2w) and n_occ entries, or -1 when minimizer lines do not pay: the largest g <= 4 that keeps
+// the mean line load at or under 10 of 16 slots, provided the table stays within max(64 MiB, 40 bytes per entry)
+MZ_HD int front_choose_g(uint32_t w, uint64_t n_occ) {
+    if (2 * w > 32) return -1;
+    for (int g = (int)(2 * w < kFrontMaxG ? 2 * w : kFrontMaxG); g >= 0; --g) {
+        const uint64_t n_lines = 1ull << (2 * w - g);
+        if (n_occ > 10 * n_lines) continue;
+        const uint64_t bytes = n_lines * kFrontSlots * 8, cap = 40 * n_occ > (64ull << 20) ? 40 * n_occ : (64ull << 20);
+        return bytes <= cap ? g : -1;
+    }
+    return -1;
+}
+
 // ---- negative filter in the slack of a record's offset block --------------------------------------------
 // The words of the partitioned-EF block between the end of its unary part and its bit planes are unused (typically 3-4 of
 // the 7: ~45 members, span ~130).  They hold a one-probe Bloom filter over (member index, inner flank) of every entry of

@@ -114,7 +114,7 @@ constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFF
 // S.qinfo[i]: the flank16 an entry must show for item i (mz_common.hpp `pos` entry), in the orientation of the canonical
 // word g*: bits 0..7 = the 4 bases left of the minimizer in g*, bits 8..15 = the 4 bases right of it | offset << 16 |
 // kQMulti once a second bucket entry survived the flank filter
-constexpr uint32_t kQOffShift = 16, kQOffMask = 0x1Fu, kQMulti = 0x80000000u;
+constexpr uint32_t kQOffShift = 16, kQOffMask = 0x1Fu, kQMulti = 0x80000000u, kQIdle = 0x40000000u; // kQIdle: no query in this slot
 __device__ __forceinline__ uint32_t query_flank(uint64_t g, uint32_t off, uint32_t w) {
     const uint32_t ql = (uint32_t)(off >= kFlankBases ? g >> (2 * (off - kFlankBases)) : g << (2 * (kFlankBases - off))) & 0xFFu;
     const uint32_t qr = (uint32_t)(g >> (2 * (off + w))) & 0xFFu;
@@ -308,7 +308,7 @@ template <class SC>
 __device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, uint64_t fw, uint64_t rc, Minimizer mn, uint32_t w, bool valid) {
     S.fw[i] = fw;
     S.slot[i] = mn.word;
-    S.qinfo[i] = query_flank(fw <= rc ? fw : rc, mn.offset, w) | (mn.offset << kQOffShift);
+    S.qinfo[i] = query_flank(fw <= rc ? fw : rc, mn.offset, w) | (mn.offset << kQOffShift) | (valid ? 0u : kQIdle);
     S.best[i] = kBestNone;
     S.n[i] = valid ? 0u : kNIdle;
 }
@@ -318,6 +318,74 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
     SC::sync();
     if constexpr (kStopAfter == 1) return;
+    // ---- SF: minimizer lines.  ONE gather answers membership and, for most keys, hands over the bucket's entries with their
+    //          flank fingerprints: eight lanes fetch the 128-byte line of a query with one coalesced 16-byte load each and
+    //          test two slots each; the lane that holds the first surviving entry records the candidate for S5, the lane
+    //          that holds a marker routes the query to the skew index (S4) or, for a bucket that did not fit its line, hands
+    //          its range in the entry array to S3.  A query none of whose line's slots carries its key is a miss.
+    if (ix.front.lines != nullptr) {
+        constexpr int kFR = 8;                                 // rounds (of 8 queries) whose lines are in flight together
+        constexpr uint32_t kRounds = SC::NT * kQpt / 8;        // 8 queries per 64 lanes and round
+        static_assert(SC::NT == 64 || SC::NT % 64 == 0, "rounds are per wavefront");
+        const uint32_t lane = t & 63, sub = lane & 7, grp = lane >> 3, g = ix.front.g;
+        const uint32_t wave_q0 = (t >> 6) * (64 * kQpt);      // first item of this wave's share of the tile
+        const uint64_t last_km_start = ix.total_len - k;
+        for (uint32_t r0 = 0; r0 < kRounds / (SC::NT / 64); r0 += kFR) {
+            ulonglong2 sl[kFR];
+            uint32_t qn[kFR], qi[kFR], keyl[kFR];
+#pragma unroll
+            for (int a = 0; a < kFR; ++a) { // all loads of the batch first
+                qn[a] = wave_q0 + (r0 + a) * 8 + grp;
+                const uint32_t key = (uint32_t)S.slot[qn[a]];
+                qi[a] = S.qinfo[qn[a]];
+                keyl[a] = key & ((1u << g) - 1);
+                const uint64_t line = (qi[a] & kQIdle) ? 0ull : (uint64_t)(key >> g); // idle slots read line 0 (always there)
+                sl[a] = *reinterpret_cast<const ulonglong2 *>(ix.front.lines + line * kFrontSlots + 2 * sub);
+            }
+#pragma unroll
+            for (int a = 0; a < kFR; ++a) {
+                const uint32_t q = qn[a], off_a = (qi[a] >> kQOffShift) & kQOffMask, room = k - w - off_a;
+                const bool live = !(qi[a] & kQIdle);
+                const uint32_t nl = off_a < kFlankBases ? off_a : kFlankBases, nr = room < kFlankBases ? room : kFlankBases;
+                const uint32_t fmask = ((0xFFu << (2 * (kFlankBases - nl))) & 0xFFu) | (((1u << (2 * nr)) - 1) << 8);
+                const uint32_t pat = (keyl[a] << kFrontKeyShift) | ((qi[a] & 0xFFFFu) << kFrontFlankShift);      // kind 0, this key, these flanks
+                const uint32_t msk = 3u | kFrontKeyMask | (fmask << kFrontFlankShift);
+                const uint64_t e0 = sl[a].x, e1 = sl[a].y;
+                const uint32_t x0 = (uint32_t)e0 ^ pat, x1 = (uint32_t)e1 ^ pat;
+                const uint64_t p0 = (e0 >> kFrontPosShift) - (((e0 >> kFrontClsShift) & 1) ? room : off_a);
+                const uint64_t p1 = (e1 >> kFrontPosShift) - (((e1 >> kFrontClsShift) & 1) ? room : off_a);
+                const bool s0 = live && (x0 & msk) == 0 && p0 <= last_km_start; // p wraps around when the k-mer would start before base 0
+                const bool s1 = live && (x1 & msk) == 0 && p1 <= last_km_start;
+                const bool m0 = live && (x0 & kFrontKeyMask) == 0 && ((uint32_t)e0 & 3u) - 1u < 2u; // heavy or spill marker of this key
+                const bool m1 = live && (x1 & kFrontKeyMask) == 0 && ((uint32_t)e1 & 3u) - 1u < 2u;
+                const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
+                const uint32_t ga = (uint32_t)(b0 >> (8 * grp)) & 0xFFu, gb = (uint32_t)(b1 >> (8 * grp)) & 0xFFu; // this query's eight lanes
+                const bool none_before = ((ga | gb) & ((1u << sub) - 1)) == 0;                                   // slots come in pairs per lane, in line order
+                if (none_before && (s0 || s1)) { // this lane holds the first survivor in bucket order
+                    S.best[q] = s0 ? p0 : p1;
+                    if (__popc(ga) + __popc(gb) > 1) S.qinfo[q] = qi[a] | kQMulti;
+                }
+                bool heavy = false;
+                if (m0 || m1) { // a key has entries or one marker, never both
+                    const uint64_t e = m0 ? e0 : e1;
+                    if (((uint32_t)e & 3u) == kFrontHeavy) {
+                        heavy = true;
+                        S.n[q] = kNSkew;
+                    } else {
+                        const uint32_t cnt = (uint32_t)(e >> kFrontFlankShift) & 0xFFFFu;
+                        if (cnt == 0xFFFFu) { // size does not fit the marker (an index without a skew index only): exact walk
+                            S.best[q] = 0;
+                            S.qinfo[q] = qi[a] | kQMulti;
+                        } else {
+                            S.slot[q] = e >> kFrontPosShift;
+                            S.n[q] = cnt;
+                        }
+                    }
+                }
+                wave_push(S.list_b, &S.cnt_skew, heavy, q);
+            }
+        }
+    } else
     // ---- S1: minimizer -> bucket id.  Direct-address rank bitmap (2w <= 32): one dense gather, no rounds;
     //          otherwise the BBHash level loop
     if (ix.mm.direct) {
@@ -1090,6 +1158,10 @@ int device_upload(const SSHashHost &h, int device, DeviceIndex **out) {
         if ((rc = upload(d, h.skew.buckets.data(), h.skew.buckets.size(), &v.skew.buckets)) != MZ_OK) return fail(rc);
         if ((rc = upload(d, h.skew.ovf_word.data(), h.skew.ovf_word.size(), &v.skew.ovf_word)) != MZ_OK) return fail(rc);
         if ((rc = upload(d, h.skew.ovf_pos.data(), h.skew.ovf_pos.size(), &v.skew.ovf_pos)) != MZ_OK) return fail(rc);
+    }
+    if (h.front.present) {
+        v.front = h.front.view();
+        if ((rc = upload(d, h.front.lines.data(), h.front.lines.size(), &v.front.lines)) != MZ_OK) return fail(rc);
     }
     d->view = v;
     *out = d;

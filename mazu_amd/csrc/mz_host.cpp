@@ -704,6 +704,37 @@ void SkewTable::build(const uint64_t *words, const uint64_t *pos, uint64_t n, in
     }
 }
 
+int FrontTable::choose_g(uint32_t w, uint64_t n_occ, bool direct) {
+    if (!direct) return -1; // the lines are addressed by key and built from the minimizer records
+    const char *e = std::getenv("MZ_FRONT_TABLE");
+    if (e && e[0] == '0') return -1;
+    if (e && e[0] == '1') { // forced: the largest g that keeps the mean load at or under 10 slots, whatever the table size
+        if (2 * w > 32) return -1;
+        for (int g = (int)std::min<uint32_t>(2 * w, kFrontMaxG); g >= 0; --g)
+            if (n_occ <= 10 * (1ull << (2 * w - g))) return g;
+        return -1;
+    }
+    return front_choose_g(w, n_occ);
+}
+
+void FrontTable::build(const uint64_t *minrec, uint32_t w, int g_, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads) {
+    present = g_ >= 0;
+    lines.clear();
+    if (!present) return;
+    g = (uint32_t)g_;
+    const uint64_t n_lines = 1ull << (2 * w - g);
+    lines.resize(n_lines * kFrontSlots);
+    uint64_t *L = lines.data();
+    const uint32_t gg = g;
+    parallel_for(n_threads, n_lines, [=](int, uint64_t b, uint64_t e) {
+        for (uint64_t line = b; line < e; ++line) {
+            uint64_t bucket0;
+            const uint32_t members = front_line_members(minrec, gg, line, bucket0);
+            front_build_line(gg, members, bucket0, psum, entries, skew_param, L + line * kFrontSlots);
+        }
+    });
+}
+
 int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads) {
     double t0 = now_s();
     const bool timing = std::getenv("MZ_BUILD_TIMING") != nullptr;
@@ -870,6 +901,8 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     }
     pos.assign(posv.data(), n_occ, max_pos, nt);
     phase("EF + minrec + pack");
+    front.build(mm.blocks.data(), w, FrontTable::choose_g(w, n_occ, mm.direct != 0), psum.data(), posv.data(), skew_param, nt);
+    phase("minimizer lines");
     build_seconds = now_s() - t0;
     return MZ_OK;
 }
@@ -891,6 +924,7 @@ IndexView SSHashHost::view() const {
     if (has_skew) {
         v.skew = skew.view();
     }
+    v.front = front.view();
     v.starts = us.starts.data();
     return v;
 }
@@ -899,11 +933,11 @@ IndexView SSHashHost::view() const {
 uint64_t SSHashHost::num_bits() const {
     uint64_t b = 64 + us.num_bits() + buckets.num_bits() + pos.num_bits() + mm.num_bits();
     if (has_skew) b += skew.num_bits();
-    return b;
+    return b + front.num_bits();
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '1', '0'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '1', '1'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>
@@ -946,6 +980,9 @@ int SSHashHost::save(const std::string &path) const {
     putv(f, us.useq); putv(f, us.starts); putv(f, us.bv_blocks); put_ef(f, us.accum_lens);
     put_mphf(f, mm); put(f, buckets.n); put(f, buckets.n_overflow); putv(f, buckets.blocks); putv(f, buckets.ovf); put_pv(f, pos);
     if (has_skew) { put(f, skew.n_buckets); put(f, skew.n_keys); put(f, skew.fp_bits); putv(f, skew.buckets); putv(f, skew.ovf_word); putv(f, skew.ovf_pos); }
+    const uint32_t hf = front.present ? 1 : 0;
+    put(f, hf);
+    if (front.present) { put(f, front.g); putv(f, front.lines); }
     return f ? MZ_OK : (set_error("short write to %s", path.c_str()), MZ_EIO);
 }
 
@@ -1004,6 +1041,17 @@ static const char *check_loaded(const SSHashHost &h) {
         for (uint64_t p : t.ovf_pos)
             if (p > last) return "skew overflow position";
     }
+    if (h.front.present) { // every slot must point inside the entry array / the sequence
+        const FrontTable &t = h.front;
+        if (!h.mm.direct || t.g > kFrontMaxG || t.g > 2 * h.w || t.lines.size() != (1ull << (2 * h.w - t.g)) * kFrontSlots) return "minimizer lines";
+        for (uint64_t e : t.lines) {
+            const uint32_t kind = (uint32_t)e & 3u;
+            const uint64_t a = e >> kFrontPosShift;
+            if (kind == kFrontEntry && a >= us.total_len) return "minimizer line position";
+            if (kind == kFrontSpill && a + ((e >> kFrontFlankShift) & 0xFFFF) > h.pos.n && ((e >> kFrontFlankShift) & 0xFFFF) != 0xFFFF) return "minimizer line bucket range";
+            if (kind == kFrontSpill && a >= h.pos.n) return "minimizer line bucket range";
+        }
+    }
     return nullptr;
 }
 
@@ -1020,6 +1068,11 @@ int SSHashHost::load(const std::string &path) {
               get_ef(f, us.accum_lens) && get_mphf(f, mm) && get(f, buckets.n) && get(f, buckets.n_overflow) && getv(f, buckets.blocks) && getv(f, buckets.ovf) && get_pv(f, pos);
     has_skew = hs != 0;
     if (ok && has_skew) ok = get(f, skew.n_buckets) && get(f, skew.n_keys) && get(f, skew.fp_bits) && getv(f, skew.buckets) && getv(f, skew.ovf_word) && getv(f, skew.ovf_pos);
+    uint32_t hf = 0;
+    ok = ok && get(f, hf);
+    front.present = hf != 0;
+    front.lines.clear();
+    if (ok && front.present) ok = get(f, front.g) && getv(f, front.lines);
     if (!ok) {
         set_error("%s: truncated", path.c_str());
         return MZ_EIO;

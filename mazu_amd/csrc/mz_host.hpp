@@ -103,6 +103,19 @@ struct SkewTable {
     uint64_t num_bits() const { return 64 * (uint64_t)(buckets.size() + ovf_word.size() + ovf_pos.size()); }
 };
 
+// Minimizer lines (layout: FrontView in mz_common.hpp).  Built from the minimizer records, the bucket starts and the
+// entry array; the GPU builder produces the same words.
+struct FrontTable {
+    std::vector<uint64_t> lines;
+    uint32_t g = 0;
+    bool present = false;
+    // MZ_FRONT_TABLE=0 never builds the lines, =1 builds them whenever a g exists (ignoring the size rule), otherwise front_choose_g decides
+    static int choose_g(uint32_t w, uint64_t n_occ, bool direct);
+    void build(const uint64_t *minrec, uint32_t w, int g_, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads);
+    FrontView view() const { return present ? FrontView{lines.data(), (uint64_t)lines.size() / kFrontSlots, g, 0} : FrontView{nullptr, 0, 0, 0}; }
+    uint64_t num_bits() const { return present ? 64ull * lines.size() : 0; }
+};
+
 struct SSHashHost {
     UnitigSet us;
     uint32_t w = 0;
@@ -113,6 +126,7 @@ struct SSHashHost {
     PackedVec pos;    // pos
     bool has_skew = false;
     SkewTable skew;   // skew index: canonical k-mer of a heavy bucket -> global k-mer position (SkewView in mz_common.hpp)
+    FrontTable front; // minimizer lines (optional)
     uint64_t n_minimizers = 0, n_minrec_overflow = 0;
     double build_seconds = 0;
 

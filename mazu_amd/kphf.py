@@ -188,6 +188,7 @@ class SSHash:  # sshash.rs:39-51
     def n_kmers_in_skew_index(self): return lib.mz_sshash_n_kmers_in_skew_index(self._h)
     def num_bits(self): return lib.mz_sshash_num_bits(self._h)
     def minimizer_mphf_kind(self): return lib.mz_sshash_minimizer_mphf_kind(self._h)
+    def has_minimizer_lines(self): return bool(lib.mz_sshash_has_minimizer_lines(self._h))
     def device_bytes(self): return lib.mz_sshash_device_bytes(self._h)
     def to_device(self, device=0): check(lib.mz_sshash_to_device(self._h, device))
 

@@ -45,14 +45,19 @@ def _k2u_device(ix, q):
     return out, cnt.cpu().tolist()
 
 
-def test_s_eighth_headline_kernel_matches_oracle():
-    """BASELINE configs[3] at 1/8 scale (452 Mbp, 4.5 M unitigs): same kernel specialisation and index form as the headline"""
+@pytest.mark.parametrize("front", ["1", "0"])
+def test_s_eighth_headline_kernel_matches_oracle(monkeypatch, front):
+    """BASELINE configs[3] at 1/8 scale (452 Mbp, 4.5 M unitigs): same kernel specialisation and index form as the headline.
+    front=1: minimizer lines (the form the full-size sets get by the size rule, forced here); front=0: the minimizer
+    record -> entry array path with the records' negative filter (what spilled buckets and small sets use)"""
     import torch
     from mazu_amd import synth
+    monkeypatch.setenv("MZ_FRONT_TABLE", front)
     us = synth.make_unitig_set("s-eighth", device="cuda")
     assert us["total_len"] == 3_589_802_592 // 8
     ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
     assert ix.minimizer_mphf_kind() == 1 and ix.n_kmers_in_skew_index() > 0  # direct minimizer records + a populated skew table
+    assert ix.has_minimizer_lines() == (front == "1")
     assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and rep["n_kmers"] == ix.n_kmers()
     q = synth.make_query_mix(ix, us, 2_000_000, seed=11, device="cuda")                         # 50/50 NEG-U
     q1 = synth.make_query_mix(ix, us, 400_000, seed=12, device="cuda", neg_kind="sub1")        # 200 k positives + 200 k NEG-1
@@ -99,7 +104,7 @@ def _full_size_properties(preset, n_q):
     us = synth.make_unitig_set(preset, device="cuda")
     assert us["total_len"] == synth.PRESETS[preset]["total_len"] and us["n_unitigs"] == synth.PRESETS[preset]["n_unitigs"]
     ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
-    assert ix.minimizer_mphf_kind() == 1
+    assert ix.minimizer_mphf_kind() == 1 and ix.has_minimizer_lines()
     assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and rep["n_kmers"] == ix.n_kmers()
     dev = torch.device("cuda")
     g = torch.Generator(device=dev)
@@ -148,7 +153,7 @@ class FlatIndexFile:
 
     def __init__(self, data):
         self.d = bytearray(data)
-        assert bytes(self.d[:8]) == b"MZSSH010"
+        assert bytes(self.d[:8]) == b"MZSSH011"
         o = 8
         self.k, self.w = struct.unpack_from("<II", self.d, o); o += 8
         self.seed, self.skew_param, self.total_len, self.n_unitigs, self.n_minimizers = struct.unpack_from("<5Q", self.d, o); o += 40
@@ -171,6 +176,10 @@ class FlatIndexFile:
         if self.has_skew:
             o += 8 + 8 + 4  # n_buckets, n_keys, fp_bits
             o = vec("skew_buckets", o); o = vec("skew_ovf_word", o); o = vec("skew_ovf_pos", o)
+        (self.has_front,) = struct.unpack_from("<I", self.d, o); o += 4
+        if self.has_front:
+            (self.front_g,) = struct.unpack_from("<I", self.d, o); o += 4
+            o = vec("front_lines", o)
         assert o == len(self.d), (o, len(self.d))
 
     def get(self, name, i):
