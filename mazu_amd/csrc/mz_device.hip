@@ -110,7 +110,7 @@ constexpr int kStopAfter = MZ_STOP_AFTER;
 #endif
 constexpr int kRecBatch = MZ_REC_BATCH; // minimizer records in flight per lane (S1)
 // S.n[i]: bucket size (< kNSkew), or one of the markers below (kNIdle: no query in this slot)
-constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu;
+constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu, kNPending = 0xFFFFFFFCu; // kNPending: SF left a marker slot in slot[i]
 // S.qinfo[i]: the flank16 an entry must show for item i (mz_common.hpp `pos` entry), in the orientation of the canonical
 // word g*: bits 0..7 = the 4 bases left of the minimizer in g*, bits 8..15 = the 4 bases right of it | offset << 16 |
 // kQMulti once a second bucket entry survived the flank filter
@@ -304,13 +304,30 @@ template <class SC>
 __device__ __forceinline__ void tile_begin(TileLdsT<SC::NT> &S) {
     if (SC::tid() == 0) { S.cnt_a = 0; S.cnt_b = 0; S.cnt_skew = 0; }
 }
+// flank bits of a query that its k-mer actually covers, as a mask over flank16 (minimizer at offset `off` of the canonical word)
+__device__ __forceinline__ uint32_t flank_cover_mask(uint32_t off, uint32_t room) {
+    const uint32_t nl = off < kFlankBases ? off : kFlankBases, nr = room < kFlankBases ? room : kFlankBases;
+    return ((0xFFu << (2 * (kFlankBases - nl))) & 0xFFu) | (((1u << (2 * nr)) - 1) << 8);
+}
+constexpr uint32_t kFrontIdleKey = 0x1F0u << kFrontKeyShift; // key field no slot can show (real keys use g <= 4 bits, empty slots all nine)
+
+// `lines`: the index has minimizer lines (keys fit 32 bits): the slot pattern of the query and its mask are prepared here,
+// once per query, for stage SF (pattern in the high half of slot[], mask in eoff[], which S3 only needs later)
 template <class SC>
-__device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, uint64_t fw, uint64_t rc, Minimizer mn, uint32_t w, bool valid) {
+__device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, uint64_t fw, uint64_t rc, Minimizer mn, uint32_t k, uint32_t w, bool valid,
+                                               bool lines) {
+    const uint32_t fl = query_flank(fw <= rc ? fw : rc, mn.offset, w);
     S.fw[i] = fw;
-    S.slot[i] = mn.word;
-    S.qinfo[i] = query_flank(fw <= rc ? fw : rc, mn.offset, w) | (mn.offset << kQOffShift) | (valid ? 0u : kQIdle);
+    S.qinfo[i] = fl | (mn.offset << kQOffShift) | (valid ? 0u : kQIdle);
     S.best[i] = kBestNone;
     S.n[i] = valid ? 0u : kNIdle;
+    if (lines) {
+        const uint32_t pat = (fl << kFrontFlankShift) | (valid ? 0u : kFrontIdleKey); // kind 0 (entry), these flanks; the key's low bits are added in SF
+        S.slot[i] = mn.word | ((uint64_t)pat << 32);
+        S.eoff[i] = 3u | kFrontKeyMask | (flank_cover_mask(mn.offset, k - w - mn.offset) << kFrontFlankShift);
+    } else {
+        S.slot[i] = mn.word;
+    }
 }
 
 template <class SC>
@@ -320,70 +337,76 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     if constexpr (kStopAfter == 1) return;
     // ---- SF: minimizer lines.  ONE gather answers membership and, for most keys, hands over the bucket's entries with their
     //          flank fingerprints: eight lanes fetch the 128-byte line of a query with one coalesced 16-byte load each and
-    //          test two slots each; the lane that holds the first surviving entry records the candidate for S5, the lane
-    //          that holds a marker routes the query to the skew index (S4) or, for a bucket that did not fit its line, hands
-    //          its range in the entry array to S3.  A query none of whose line's slots carries its key is a miss.
+    //          test two slots each against the query's slot pattern (one xor/and/compare per slot).  The lane that holds the
+    //          first surviving entry in bucket order, or the key's marker, only parks that slot in the query's LDS words; a
+    //          dense pass afterwards (one lane per query, all lanes busy) turns parked slots into the candidate position for
+    //          S5, a skew-index request for S4, or -- for a bucket that did not fit its line -- its range in the entry array
+    //          for S3.  A query none of whose line's slots carries its key is a miss.
     if (ix.front.lines != nullptr) {
         constexpr int kFR = 8;                                 // rounds (of 8 queries) whose lines are in flight together
-        constexpr uint32_t kRounds = SC::NT * kQpt / 8;        // 8 queries per 64 lanes and round
-        static_assert(SC::NT == 64 || SC::NT % 64 == 0, "rounds are per wavefront");
+        constexpr uint32_t kRounds = 64 * kQpt / 8;            // per wavefront: 8 queries per 64 lanes and round
         const uint32_t lane = t & 63, sub = lane & 7, grp = lane >> 3, g = ix.front.g;
         const uint32_t wave_q0 = (t >> 6) * (64 * kQpt);      // first item of this wave's share of the tile
-        const uint64_t last_km_start = ix.total_len - k;
-        for (uint32_t r0 = 0; r0 < kRounds / (SC::NT / 64); r0 += kFR) {
+        const unsigned long long grp_mask = 0xFFull << (lane & ~7u), low_mask = grp_mask & ((1ull << lane) - 1); // my query's lanes / those before me
+        for (uint32_t r0 = 0; r0 < kRounds; r0 += kFR) { // (a rolling window of requests instead of batches measured the same: the gathers are bandwidth-bound)
             ulonglong2 sl[kFR];
-            uint32_t qn[kFR], qi[kFR], keyl[kFR];
+            uint32_t pat[kFR];
 #pragma unroll
             for (int a = 0; a < kFR; ++a) { // all loads of the batch first
-                qn[a] = wave_q0 + (r0 + a) * 8 + grp;
-                const uint32_t key = (uint32_t)S.slot[qn[a]];
-                qi[a] = S.qinfo[qn[a]];
-                keyl[a] = key & ((1u << g) - 1);
-                const uint64_t line = (qi[a] & kQIdle) ? 0ull : (uint64_t)(key >> g); // idle slots read line 0 (always there)
-                sl[a] = *reinterpret_cast<const ulonglong2 *>(ix.front.lines + line * kFrontSlots + 2 * sub);
+                const uint64_t kp = S.slot[wave_q0 + (r0 + a) * 8 + grp];     // key | pattern << 32 (an idle slot has key 0: line 0 is always there)
+                const uint32_t key = (uint32_t)kp;
+                pat[a] = (uint32_t)(kp >> 32) | ((key & ((1u << g) - 1)) << kFrontKeyShift);
+                sl[a] = *reinterpret_cast<const ulonglong2 *>(ix.front.lines + (uint64_t)(key >> g) * kFrontSlots + 2 * sub);
             }
 #pragma unroll
             for (int a = 0; a < kFR; ++a) {
-                const uint32_t q = qn[a], off_a = (qi[a] >> kQOffShift) & kQOffMask, room = k - w - off_a;
-                const bool live = !(qi[a] & kQIdle);
-                const uint32_t nl = off_a < kFlankBases ? off_a : kFlankBases, nr = room < kFlankBases ? room : kFlankBases;
-                const uint32_t fmask = ((0xFFu << (2 * (kFlankBases - nl))) & 0xFFu) | (((1u << (2 * nr)) - 1) << 8);
-                const uint32_t pat = (keyl[a] << kFrontKeyShift) | ((qi[a] & 0xFFFFu) << kFrontFlankShift);      // kind 0, this key, these flanks
-                const uint32_t msk = 3u | kFrontKeyMask | (fmask << kFrontFlankShift);
+                const uint32_t q = wave_q0 + (r0 + a) * 8 + grp, msk = S.eoff[q];
                 const uint64_t e0 = sl[a].x, e1 = sl[a].y;
-                const uint32_t x0 = (uint32_t)e0 ^ pat, x1 = (uint32_t)e1 ^ pat;
-                const uint64_t p0 = (e0 >> kFrontPosShift) - (((e0 >> kFrontClsShift) & 1) ? room : off_a);
-                const uint64_t p1 = (e1 >> kFrontPosShift) - (((e1 >> kFrontClsShift) & 1) ? room : off_a);
-                const bool s0 = live && (x0 & msk) == 0 && p0 <= last_km_start; // p wraps around when the k-mer would start before base 0
-                const bool s1 = live && (x1 & msk) == 0 && p1 <= last_km_start;
-                const bool m0 = live && (x0 & kFrontKeyMask) == 0 && ((uint32_t)e0 & 3u) - 1u < 2u; // heavy or spill marker of this key
-                const bool m1 = live && (x1 & kFrontKeyMask) == 0 && ((uint32_t)e1 & 3u) - 1u < 2u;
+                const uint32_t x0 = (uint32_t)e0 ^ pat[a], x1 = (uint32_t)e1 ^ pat[a];
+                const bool s0 = (x0 & msk) == 0, s1 = (x1 & msk) == 0; // an entry (kind 0) of this key whose flanks agree
                 const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
-                const uint32_t ga = (uint32_t)(b0 >> (8 * grp)) & 0xFFu, gb = (uint32_t)(b1 >> (8 * grp)) & 0xFFu; // this query's eight lanes
-                const bool none_before = ((ga | gb) & ((1u << sub) - 1)) == 0;                                   // slots come in pairs per lane, in line order
-                if (none_before && (s0 || s1)) { // this lane holds the first survivor in bucket order
-                    S.best[q] = s0 ? p0 : p1;
-                    if (__popc(ga) + __popc(gb) > 1) S.qinfo[q] = qi[a] | kQMulti;
+                if ((s0 || s1) && ((b0 | b1) & low_mask) == 0) {       // slots run in line order, two per lane: this lane holds the first survivor
+                    S.best[q] = s0 ? e0 : e1;
+                    if (__popcll(b0 & grp_mask) + __popcll(b1 & grp_mask) > 1) atomicOr(&S.qinfo[q], kQMulti);
                 }
-                bool heavy = false;
-                if (m0 || m1) { // a key has entries or one marker, never both
-                    const uint64_t e = m0 ? e0 : e1;
-                    if (((uint32_t)e & 3u) == kFrontHeavy) {
-                        heavy = true;
-                        S.n[q] = kNSkew;
-                    } else {
-                        const uint32_t cnt = (uint32_t)(e >> kFrontFlankShift) & 0xFFFFu;
-                        if (cnt == 0xFFFFu) { // size does not fit the marker (an index without a skew index only): exact walk
-                            S.best[q] = 0;
-                            S.qinfo[q] = qi[a] | kQMulti;
-                        } else {
-                            S.slot[q] = e >> kFrontPosShift;
-                            S.n[q] = cnt;
-                        }
-                    }
+                // heavy or spill marker of this key: same key bits, kind 1 or 2 (a key has entries or one marker, never both)
+                const bool m0 = (x0 & (kFrontKeyMask | 3u)) - 1u < 2u, m1 = (x1 & (kFrontKeyMask | 3u)) - 1u < 2u;
+                if (m0 || m1) {
+                    S.slot[q] = m0 ? e0 : e1;
+                    S.n[q] = kNPending;
                 }
-                wave_push(S.list_b, &S.cnt_skew, heavy, q);
             }
+        }
+        SC::sync();
+#pragma unroll
+        for (int qq = 0; qq < kQpt; ++qq) { // parked slots -> what the later stages expect
+            const uint32_t i = qq * SC::NT + t;
+            const unsigned long long b = S.best[i];
+            const uint32_t nn = S.n[i];
+            if (b != kBestNone) {
+                const uint32_t qi = S.qinfo[i], off_a = (qi >> kQOffShift) & kQOffMask;
+                const uint64_t p = (b >> kFrontPosShift) - (((b >> kFrontClsShift) & 1) ? k - w - off_a : off_a);
+                const bool in_range = p <= ix.total_len - k;          // p wraps around when the k-mer would start before base 0
+                S.best[i] = in_range ? p : 0;                          // out of range (first or last bases of the sequence only): exact walk
+                if (!in_range) S.qinfo[i] = qi | kQMulti;
+            }
+            bool heavy = false;
+            if (nn == kNPending) {
+                const uint64_t e = S.slot[i];
+                const uint32_t cnt = (uint32_t)(e >> kFrontFlankShift) & 0xFFFFu;
+                heavy = ((uint32_t)e & 3u) == kFrontHeavy;
+                if (heavy) {
+                    S.n[i] = kNSkew;
+                } else if (cnt == 0xFFFFu) { // size does not fit the marker (an index without a skew index only): exact walk
+                    S.best[i] = 0;
+                    S.qinfo[i] |= kQMulti;
+                    S.n[i] = 0;
+                } else {
+                    S.slot[i] = e >> kFrontPosShift;
+                    S.n[i] = cnt;
+                }
+            }
+            wave_push(S.list_b, &S.cnt_skew, heavy, i);
         }
     } else
     // ---- S1: minimizer -> bucket id.  Direct-address rank bitmap (2w <= 32): one dense gather, no rounds;
@@ -714,7 +737,7 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
             uint32_t i = q * kBlock + t;
             uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
             uint64_t rc = kmer_rc(fw, k);
-            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), w, i < n_valid);
+            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), k, w, i < n_valid, ix.front.lines != nullptr);
         }
         tile_resolve<BlockScope>(S, ix);
         // ---- S5: coalesced 16-byte stores
@@ -761,7 +784,7 @@ __global__ __launch_bounds__(kBlock, MZ_WAVES_PER_EU) void k2u_wave_kernel(Index
             const uint32_t i = q * SC::NT + t;
             const uint64_t fw = i < n_valid ? (fwq[q] & kmask) : 0;
             const uint64_t rc = kmer_rc(fw, k);
-            tile_set_query<SC>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), w, i < n_valid);
+            tile_set_query<SC>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), k, w, i < n_valid, ix.front.lines != nullptr);
         }
         tile_resolve<SC>(S, ix);
 #pragma unroll
@@ -794,7 +817,7 @@ __global__ __launch_bounds__(kBlock) void k2u_compact_kernel(IndexView ix, const
             uint32_t i = q * kBlock + t;
             uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
             uint64_t rc = kmer_rc(fw, k);
-            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), w, i < n_valid);
+            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), k, w, i < n_valid, ix.front.lines != nullptr);
         }
         tile_resolve<BlockScope>(S, ix);
 #pragma unroll
@@ -969,7 +992,7 @@ __global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const u
                 rc = kmer_rc(fw, k);
                 if (query) mn = window_minimizer(R, i, fw, rc, k, w);
             }
-            tile_set_query<SC>(S, it, fw, rc, mn, w, query);
+            tile_set_query<SC>(S, it, fw, rc, mn, k, w, query, ix.front.lines != nullptr);
             if (state[q] == 1) { // non-ACGT window: reported, never queried
                 mz_k2upos sk = make_none();
                 sk.match = MZ_SKIPPED;
@@ -1037,8 +1060,8 @@ __global__ __launch_bounds__(kBlock, 4) void validate_self_kernel(IndexView ix, 
                 if (valid[q]) { fw = read_kmer_i(ix.seqbv, p, k); rc = kmer_rc(fw, k); }
             }
             Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
-            tile_set_query<SC>(S, i, fw, rc, mn, w, valid[q]);          // km
-            tile_set_query<SC>(S, kPos + i, rc, fw, mn, w, valid[q]);   // km.swap(): same canonical k-mer, same minimizer
+            tile_set_query<SC>(S, i, fw, rc, mn, k, w, valid[q], ix.front.lines != nullptr);          // km
+            tile_set_query<SC>(S, kPos + i, rc, fw, mn, k, w, valid[q], ix.front.lines != nullptr);   // km.swap(): same canonical k-mer, same minimizer
         }
         tile_resolve<SC>(S, ix);
 #pragma unroll
