@@ -108,6 +108,9 @@ constexpr int kStopAfter = MZ_STOP_AFTER;
 #ifndef MZ_WAVES_PER_EU
 #define MZ_WAVES_PER_EU 4
 #endif
+#ifndef MZ_READS_WAVES
+#define MZ_READS_WAVES 2 // minimum waves per SIMD the reads kernel is compiled for: 2 leaves the register allocator at ~160 VGPRs = 3 waves, measured best (3 -> 146 VGPRs: -3 %, unbounded -> 169 VGPRs = 2 waves: -22 %)
+#endif
 constexpr int kRecBatch = MZ_REC_BATCH; // minimizer records in flight per lane (S1)
 // S.n[i]: bucket size (< kNSkew), or one of the markers below (kNIdle: no query in this slot)
 constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu, kNPending = 0xFFFFFFFCu; // kNPending: SF left a marker slot in slot[i]
@@ -913,7 +916,7 @@ __device__ __forceinline__ Minimizer window_minimizer(const ReadsLds<H> &R, uint
 // lookup is cheaper than a second staged pass.  Streaming requests therefore take this same path; by
 // the reference's own contract (and for every unique-k-mer set) the results are the same.
 template <uint32_t KW>
-__global__ __launch_bounds__(kBlock) void k2u_reads_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
+__global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
                                                            const uint64_t *__restrict__ read_offsets,
                                                            const uint64_t *__restrict__ kmer_offsets, uint64_t n_reads,
                                                            mz_k2upos *__restrict__ out, mz_counts *counts) {

@@ -28,6 +28,7 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--neg-frac", type=float, default=0.5)
 ap.add_argument("--neg-kind", default="uniform")
 ap.add_argument("--no-compare", action="store_true")
+ap.add_argument("--reads", type=int, default=0, help="time mz_sshash_k2u_reads_device on this many 150-bp reads instead of point queries")
 ap.add_argument("variants", nargs="+", help="name=path/to/lib.so")
 args = ap.parse_args()
 
@@ -39,14 +40,21 @@ starts = us["starts"].cpu().numpy().view(np.uint64)
 ix = M.SSHash.from_unitig_set_on_device(M.UnitigSet.from_packed(words, us["total_len"], starts, 31), 15, 32)
 ix.to_device(0)
 print(f"index: {ix.device_bytes() / 1e9:.2f} GB, lines={ix.has_minimizer_lines()}", flush=True)
-q = synth.make_query_mix(ix, us, args.batch, seed=1000, device=dev, neg_frac=args.neg_frac, neg_kind=args.neg_kind)
 stream = torch.cuda.current_stream(dev)
+if args.reads:
+    bases, ro = synth.make_reads(us, args.reads, 150, seed=2000, device=dev)
+    ko = synth.kmer_offsets(ro, 31)
+    args.batch = int(ko[-1])
+else:
+    q = synth.make_query_mix(ix, us, args.batch, seed=1000, device=dev, neg_frac=args.neg_frac, neg_kind=args.neg_kind)
 libs = {}
 for v in args.variants:
     name, path = v.split("=", 1)
     L = C.CDLL(os.path.abspath(path))
     L.mz_sshash_k2u_batch_device.restype = C.c_int
     L.mz_sshash_k2u_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mz_sshash_k2u_reads_device.restype = C.c_int
+    L.mz_sshash_k2u_reads_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     libs[name] = L
 outs = {n: torch.zeros(args.batch * 2, dtype=torch.int64, device=dev) for n in libs} if not args.no_compare else {}
 scratch = torch.zeros(args.batch * 2, dtype=torch.int64, device=dev)
@@ -54,7 +62,11 @@ cnt = torch.zeros(3, dtype=torch.int64, device=dev)
 
 
 def run(L, out):
-    rc = L.mz_sshash_k2u_batch_device(ix._h, q.data_ptr(), q.numel(), out.data_ptr(), cnt.data_ptr(), stream.cuda_stream)
+    if args.reads:
+        rc = L.mz_sshash_k2u_reads_device(ix._h, bases.data_ptr(), bases.numel(), ro.data_ptr(), ko.data_ptr(), ro.numel() - 1, 1, out.data_ptr(),
+                                          cnt.data_ptr(), stream.cuda_stream)
+    else:
+        rc = L.mz_sshash_k2u_batch_device(ix._h, q.data_ptr(), q.numel(), out.data_ptr(), cnt.data_ptr(), stream.cuda_stream)
     assert rc == 0, rc
 
 
