@@ -160,6 +160,56 @@ def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads, target_s=8.0):
                 n_single=n1, ns_single=dt1 / n1 * 1e9)
 
 
+# ------------------------------------------------------------------------------------------------ projection (the step after k2u)
+def bench_projection(ix, us, d_recs, n, dev, torch, np, steps=5):
+    """mz_u2pos_project_device over the K2UPos records of the headline batch; returns M MappedRefPos records per second"""
+    import ctypes as C
+    from mazu_amd._capi import check, lib
+    n_u = us["n_unitigs"]
+    starts = us["starts"]
+    # one forward/backward occurrence per unitig on a single reference laid out like the unitig concatenation
+    pos = starts[:-1].clone()
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    fwd = torch.randint(0, 2, (n_u,), generator=g, device=dev, dtype=torch.int64)
+    pos_bits, ref_bits = int(us["total_len"]).bit_length(), 1
+    width, ref_shift = 1 + pos_bits + ref_bits, pos_bits + 1
+    enc = (pos << 1) | fwd                                               # ref_id 0: UnitigOcc::encode_piscem, src/spt_compact.rs:90-96
+    bit = torch.arange(n_u, device=dev, dtype=torch.int64) * width
+    wi, sh = bit >> 6, bit & 63
+    words = torch.zeros((n_u * width + 63) // 64 + 2, dtype=torch.int64, device=dev)
+    words.index_add_(0, wi, enc << sh)                                   # disjoint bit fields: addition is bitwise or
+    spill = (sh + width) > 64
+    words.index_add_(0, wi[spill] + 1, enc[spill] >> (64 - sh[spill]))
+    offs = np.arange(n_u + 1, dtype=np.uint64)
+    words_h = words.cpu().numpy().view(np.uint64)
+    u = C.c_void_p()
+    check(lib.mz_u2pos_piscem_new(words_h.ctypes.data, n_u, width, ref_shift, (1 << pos_bits) - 1, offs.ctypes.data, 64, n_u, C.byref(u)))
+    try:
+        check(lib.mz_u2pos_to_device(u, dev.index))
+        stream = torch.cuda.current_stream(dev)
+        d_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        d_out = torch.empty(2 * n, dtype=torch.int64, device=dev)        # at most one record per query here
+        k = us["k"]
+
+        def step():
+            check(lib.mz_u2pos_project_device(u, k, d_recs.data_ptr(), n, d_off.data_ptr(), d_out.data_ptr(), n, stream.cuda_stream))
+        step()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(steps):
+            step()
+        b.record(stream)
+        torch.cuda.synchronize(dev)
+        total = int(d_off[n].item())
+        ms = a.elapsed_time(b) / steps
+        return {"table": f"PiscemUnitigTable, {n_u} unitigs x 1 occurrence, {width} bits each", "records_per_launch": total, "ms_per_launch": round(ms, 4),
+                "M_records_per_s": round(total / ms / 1e3, 1), "M_queries_per_s": round(n / ms / 1e3, 1)}
+    finally:
+        lib.mz_u2pos_free(u)
+
+
 # ------------------------------------------------------------------------------------------------ reads mode
 def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
     """BASELINE config 3: reads -> every k-mer window, results identical to independent k2u calls"""
@@ -363,6 +413,10 @@ def main():
             res["mixes_M_kmers_per_s_one_gpu"] = mixes
             step()  # `out` holds the headline batch's results again for the parity check below
             torch.cuda.synchronize(dev)
+        if not args.no_extra_mixes:
+            # the step after k2u (get_ref_pos: PiscemUnitigTable occurrences -> MappedRefPos, src/index.rs:156-216) on the headline batch's
+            # records: a synthetic tiling in which every unitig occurs once, occurrences packed into the minimal number of bits
+            res["projection"] = bench_projection(ix, us, out, batch, dev, torch, np)
         if n_gpus == 1 and not args.no_cpu_baseline:
             cores = M.lib.mz_host_threads()  # hardware threads capped by the cgroup CPU quota of this box
             q_host = q[: (args.cpu_sample or batch)].cpu().numpy().view(np.uint64)

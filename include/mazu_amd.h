@@ -207,9 +207,16 @@ typedef struct mz_mapped_ref_pos {
     uint32_t o;
     uint32_t query;
 } mz_mapped_ref_pos;
-typedef struct mz_u2pos mz_u2pos; /* DenseUnitigTable as U2Pos, src/index/dense_unitig_table.rs:12-76 */
+typedef struct mz_u2pos mz_u2pos; /* DenseUnitigTable (src/index/dense_unitig_table.rs:12-76) or PiscemUnitigTable (:110-153) as U2Pos */
 /* ctable: pufferfish 64-bit occurrences [63]=fwd [62:32]=pos [31:0]=ref (index.rs:315-346); contig_offsets: n_unitigs+1 */
 int mz_u2pos_dense_new(const uint64_t *ctable, uint64_t n_occs, const uint64_t *contig_offsets, uint64_t n_unitigs, mz_u2pos **out);
+/* PiscemUnitigTable as U2Pos (src/index/dense_unitig_table.rs:110-153): occurrences packed into occ_width bits each,
+ * (ref_id << ref_shift) | (pos << 1) | forward (UnitigOcc::encode_piscem, src/spt_compact.rs:83-112; pos_mask as :134-141),
+ * element j at bit j * occ_width of ctable_words; contig_offsets_words: n_unitigs+1 offsets of offsets_width bits each
+ * (the packed IntVector of src/index/piscem_index.rs:30-31; pass 64 for plain words).  The projection entry points below
+ * work on either kind of table; the occurrences stay packed in HBM. */
+int mz_u2pos_piscem_new(const uint64_t *ctable_words, uint64_t n_occs, uint32_t occ_width, uint32_t ref_shift, uint64_t pos_mask,
+                        const uint64_t *contig_offsets_words, uint32_t offsets_width, uint64_t n_unitigs, mz_u2pos **out);
 void mz_u2pos_free(mz_u2pos *u);
 uint64_t mz_u2pos_n_unitig_occs(const mz_u2pos *u, uint64_t ui); /* n_unitig_occs, dense_unitig_table.rs:69-71 */
 uint64_t mz_u2pos_num_total_occs(const mz_u2pos *u);             /* :34-36 */

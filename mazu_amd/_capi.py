@@ -92,6 +92,7 @@ def _load():
         "mz_sshash_save": (i, [p, C.c_char_p]),
         "mz_sshash_load": (i, [C.c_char_p, p]),
         "mz_u2pos_dense_new": (i, [p, u64, p, u64, p]),
+        "mz_u2pos_piscem_new": (i, [p, u64, u32, u32, u64, p, u32, u64, p]),
         "mz_u2pos_free": (None, [p]),
         "mz_u2pos_n_unitig_occs": (u64, [p, u64]),
         "mz_u2pos_num_total_occs": (u64, [p]),

@@ -1,7 +1,8 @@
-// mz_u2pos.hip -- the step right after k2u: unitig occurrences -> reference
-// positions on the device.  Mirrors reference src/index/dense_unitig_table.rs:55-76 (DenseUnitigTable as
-// U2Pos), src/index.rs:315-346 (pufferfish 64-bit occurrence codec) and src/index.rs:184-216
-// (project_onto_u_occ).  Variable-length output: count -> exclusive scan -> fill, all on the device.
+// mz_u2pos.hip -- the step right after k2u: unitig occurrences -> reference positions on the device.
+// Mirrors reference src/index/dense_unitig_table.rs:55-76 (DenseUnitigTable as U2Pos, pufferfish 64-bit occurrence
+// codec of src/index.rs:315-346), :110-153 (PiscemUnitigTable as U2Pos, occurrences packed into the minimal number of
+// bits, src/spt_compact.rs:83-112) and src/index.rs:184-216 (project_onto_u_occ).  Variable-length output:
+// count -> exclusive scan -> fill, all on the device.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -13,11 +14,24 @@
 
 using namespace mz;
 
+// how an occurrence is stored: element j at bit j * width of `words`; width 64 + piscem == 0 is the pufferfish word
+// [63] = forward, [62:32] = position, [31:0] = reference (index.rs:334-346); piscem != 0 is
+// (ref << ref_shift) | (pos << 1) | forward (spt_compact.rs:83-112)
+struct OccCodec {
+    const uint64_t *words;
+    uint32_t width, ref_shift, piscem, pad;
+    uint64_t pos_mask;
+};
+struct DecodedOcc { uint32_t ref_id, pos; bool fwd; };
+
 struct mz_u2pos {
-    std::vector<uint64_t> ctable, offsets; // host copies (encoded_unitig_occs on the host side of the mirror)
-    uint64_t n_unitigs = 0;
+    std::vector<uint64_t> ctable, offsets; // host copies: occurrence words (packed for piscem, + 2 pad words) and plain unitig offsets
+    uint64_t n_unitigs = 0, n_occs = 0;
+    uint32_t width = 64, ref_shift = 0, piscem = 0;
+    uint64_t pos_mask = 0;
     int device = -1;
     uint64_t *d_ctable = nullptr, *d_offsets = nullptr;
+    OccCodec codec() const { return OccCodec{d_ctable, width, ref_shift, piscem, 0, pos_mask}; }
 };
 
 namespace {
@@ -35,16 +49,22 @@ constexpr int kB = 256, kItems = 4, kTileN = kB * kItems;
 
 unsigned grid_of(uint64_t n, unsigned cap = 256 * 16) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kB - 1) / kB, cap)); }
 
-// UnitigOcc::decode_pf1 (index.rs:334-346) + project_onto_u_occ (index.rs:184-216)
-__device__ __forceinline__ mz_mapped_ref_pos project(const mz_k2upos &r, uint64_t enc, uint32_t k, uint64_t query) {
-    const uint32_t ref_id = (uint32_t)(enc & 0xFFFFFFFFull);
-    const uint32_t pw = (uint32_t)(enc >> 32);
-    const uint32_t cpos = pw & 0x7FFFFFFFu;
-    const bool fwd = (pw & 0x80000000u) != 0;                         // Orientation::Forward
-    const uint32_t pos = fwd ? r.pos + cpos : cpos + (r.unitig_len - r.pos) - k;
+// occurrence j of the table: UnitigOcc::decode_pf1 (index.rs:334-346) or decode_piscem (spt_compact.rs:97-112)
+__device__ __forceinline__ DecodedOcc decode_occ(const OccCodec &c, uint64_t j) {
+    if (c.piscem) {
+        const uint64_t e = read_packed(c.words, j, c.width);
+        return DecodedOcc{(uint32_t)(e >> c.ref_shift), (uint32_t)((e >> 1) & c.pos_mask), (e & 1) != 0};
+    }
+    const uint64_t e = c.words[j];
+    const uint32_t pw = (uint32_t)(e >> 32);
+    return DecodedOcc{(uint32_t)(e & 0xFFFFFFFFull), pw & 0x7FFFFFFFu, (pw & 0x80000000u) != 0};
+}
+// project_onto_u_occ (index.rs:184-216)
+__device__ __forceinline__ mz_mapped_ref_pos project(const mz_k2upos &r, const DecodedOcc &oc, uint32_t k, uint64_t query) {
+    const uint32_t pos = oc.fwd ? r.pos + oc.pos : oc.pos + (r.unitig_len - r.pos) - k;
     uint32_t o = r.match == MZ_IDENTITY_MATCH ? 1u : 0u;             // Forward = 1, Backward = 0 (lib.rs:50-64)
-    if (!fwd) o = 1u - o;
-    return mz_mapped_ref_pos{ref_id, pos, o, (uint32_t)query};
+    if (!oc.fwd) o = 1u - o;
+    return mz_mapped_ref_pos{oc.ref_id, pos, o, (uint32_t)query};
 }
 
 __global__ __launch_bounds__(kB) void count_kernel(const mz_k2upos *__restrict__ recs, uint64_t n, const uint64_t *__restrict__ offsets,
@@ -120,7 +140,7 @@ __global__ __launch_bounds__(kB) void scan_apply(uint64_t *__restrict__ counts, 
 
 // fill: one lane per query for short lists; a query with >= 64 occurrences is walked by its whole wave
 __global__ __launch_bounds__(kB) void fill_kernel(const mz_k2upos *__restrict__ recs, uint64_t n, const uint64_t *__restrict__ table_off,
-                                                  const uint64_t *__restrict__ ctable, const uint64_t *__restrict__ out_off, uint32_t k,
+                                                  OccCodec ctable, const uint64_t *__restrict__ out_off, uint32_t k,
                                                   mz_mapped_ref_pos *__restrict__ out, uint64_t cap) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
     uint64_t n_round = (n + 63) & ~63ull;
@@ -136,7 +156,7 @@ __global__ __launch_bounds__(kB) void fill_kernel(const mz_k2upos *__restrict__ 
         const bool longl = c >= 64;
         if (c && !longl)
             for (uint64_t j = 0; j < c; ++j)
-                if (o0 + j < cap) out[o0 + j] = project(r, ctable[t0 + j], k, i);
+                if (o0 + j < cap) out[o0 + j] = project(r, decode_occ(ctable, t0 + j), k, i);
         unsigned long long lb = __ballot(longl);
         while (lb) { // wave-cooperative walk of the long lists of this wave's 64 queries
             int src = __ffsll((long long)lb) - 1;
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(kB) void fill_kernel(const mz_k2upos *__restrict__ 
             rr.unitig_len = __shfl(r.unitig_len, src); rr.match = __shfl(r.match, src);
             uint64_t so = __shfl(o0, src), sc = __shfl(c, src), st = __shfl(t0, src), sq = __shfl(i, src);
             for (uint64_t j = __lane_id(); j < sc; j += 64)
-                if (so + j < cap) out[so + j] = project(rr, ctable[st + j], k, sq);
+                if (so + j < cap) out[so + j] = project(rr, decode_occ(ctable, st + j), k, sq);
         }
     }
 }
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(kB) void fill_kernel(const mz_k2upos *__restrict__ 
 // Validate::validate_self (src/index/validate.rs:24-52) on the device: thread per reference k-mer; its k2u
 // record must project onto (ref_id, pos) through at least one occurrence of its unitig.
 __global__ __launch_bounds__(kB) void check_refs_kernel(const mz_k2upos *__restrict__ recs, uint64_t n, const uint64_t *__restrict__ table_off,
-                                                        const uint64_t *__restrict__ ctable, uint64_t n_unitigs, uint32_t k, uint32_t ref_id,
+                                                        OccCodec ctable, uint64_t n_unitigs, uint32_t k, uint32_t ref_id,
                                                         unsigned long long *report /* n, n_fail, first_fail */) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
     unsigned fails = 0;
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(kB) void check_refs_kernel(const mz_k2upos *__restr
         if ((r.match == MZ_IDENTITY_MATCH || r.match == MZ_TWIN_MATCH) && r.unitig_id < n_unitigs) {
             uint64_t a = table_off[r.unitig_id], b = table_off[r.unitig_id + 1];
             for (uint64_t j = a; j < b && !found; ++j) {
-                mz_mapped_ref_pos m = project(r, ctable[j], k, i);
+                mz_mapped_ref_pos m = project(r, decode_occ(ctable, j), k, i);
                 found = m.ref_id == ref_id && m.pos == (uint32_t)i;
             }
         }
@@ -212,7 +232,7 @@ void launch_project(const mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint
     hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(kB), 0, stream, d_tiles, n_tiles, d_tiles + n_tiles);
     hipLaunchKernelGGL(scan_apply, dim3((unsigned)n_tiles), dim3(kB), 0, stream, d_offsets, n, d_tiles, d_tiles + n_tiles);
     if (d_out && out_cap)
-        hipLaunchKernelGGL(fill_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->d_ctable, d_offsets, k, d_out, out_cap);
+        hipLaunchKernelGGL(fill_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->codec(), d_offsets, k, d_out, out_cap);
 }
 
 int ensure_u2pos_device(mz_u2pos *u, int device) {
@@ -250,6 +270,44 @@ int mz_u2pos_dense_new(const uint64_t *ctable, uint64_t n_occs, const uint64_t *
     u->ctable.assign(ctable, ctable + n_occs);
     u->offsets.assign(contig_offsets, contig_offsets + n_unitigs + 1);
     u->n_unitigs = n_unitigs;
+    u->n_occs = n_occs;
+    *out = u;
+    return MZ_OK;
+}
+
+// PiscemUnitigTable (dense_unitig_table.rs:110-153): `ctable_words` holds n_occs occurrences of `occ_width` bits each (the IntVector the
+// reference fills in spt_compact.rs:145-160), `contig_offsets_words` n_unitigs + 1 offsets of `offsets_width` bits each (the packed
+// IntVector of piscem_index.rs:30-31; 64 = plain words).  The occurrences stay packed in HBM; the offsets are unpacked once here.
+int mz_u2pos_piscem_new(const uint64_t *ctable_words, uint64_t n_occs, uint32_t occ_width, uint32_t ref_shift, uint64_t pos_mask,
+                        const uint64_t *contig_offsets_words, uint32_t offsets_width, uint64_t n_unitigs, mz_u2pos **out) {
+    if (!out || !contig_offsets_words || (n_occs && !ctable_words)) { set_error("null argument"); return MZ_EINVAL; }
+    *out = nullptr;
+    if (occ_width == 0 || occ_width > 64 || offsets_width == 0 || offsets_width > 64 || ref_shift == 0 || ref_shift >= 64 ||
+        occ_width - ref_shift > 32 || ref_shift - 1 > 32) { // reference id and position are 32-bit fields of MappedRefPos here
+        set_error("piscem occurrence table: unsupported widths (occ %u, ref_shift %u, offsets %u)", occ_width, ref_shift, offsets_width);
+        return MZ_EINVAL;
+    }
+    mz_u2pos *u = new (std::nothrow) mz_u2pos();
+    if (!u) return MZ_ENOMEM;
+    u->offsets.resize(n_unitigs + 1);
+    {   // offsets: the caller's array is exactly ceil((n+1) * width / 64) words, so the last element is read without the pad word read_packed assumes
+        const uint64_t nw = ((n_unitigs + 1) * offsets_width + 63) / 64;
+        std::vector<uint64_t> tmp(contig_offsets_words, contig_offsets_words + nw);
+        tmp.resize(nw + 2, 0);
+        for (uint64_t i = 0; i <= n_unitigs; ++i) u->offsets[i] = read_packed(tmp.data(), i, offsets_width);
+    }
+    for (uint64_t i = 0; i < n_unitigs; ++i)
+        if (u->offsets[i + 1] < u->offsets[i]) { delete u; set_error("contig offsets not monotone at %llu", (unsigned long long)i); return MZ_ENOTMONOTONE; }
+    if (u->offsets[n_unitigs] > n_occs) { delete u; set_error("contig offsets exceed the occurrence table"); return MZ_EINVAL; }
+    const uint64_t nw = (n_occs * occ_width + 63) / 64;
+    u->ctable.assign(ctable_words, ctable_words + nw);
+    u->ctable.resize(nw + 2, 0); // pad: a packed read may touch the following word
+    u->n_unitigs = n_unitigs;
+    u->n_occs = n_occs;
+    u->width = occ_width;
+    u->ref_shift = ref_shift;
+    u->pos_mask = pos_mask;
+    u->piscem = 1;
     *out = u;
     return MZ_OK;
 }
@@ -260,7 +318,7 @@ void mz_u2pos_free(mz_u2pos *u) {
     delete u;
 }
 uint64_t mz_u2pos_n_unitig_occs(const mz_u2pos *u, uint64_t ui) { return ui < u->n_unitigs ? u->offsets[ui + 1] - u->offsets[ui] : 0; }
-uint64_t mz_u2pos_num_total_occs(const mz_u2pos *u) { return u->ctable.size(); }
+uint64_t mz_u2pos_num_total_occs(const mz_u2pos *u) { return u->n_occs; }
 
 int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets, mz_mapped_ref_pos *d_out,
                             uint64_t out_cap, void *stream_) {
@@ -323,7 +381,7 @@ int mz_u2pos_check_refs_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs,
     if (rc != MZ_OK) return rc;
     U2_HIP(hipSetDevice(u->device));
     hipLaunchKernelGGL(check_refs_kernel, dim3(grid_of(std::max<uint64_t>(n, 1))), dim3(kB), 0, (hipStream_t)stream_, d_recs, n, u->d_offsets,
-                       u->d_ctable, u->n_unitigs, k, ref_id, (unsigned long long *)d_report);
+                       u->codec(), u->n_unitigs, k, ref_id, (unsigned long long *)d_report);
     U2_HIP(hipGetLastError());
     return MZ_OK;
 }

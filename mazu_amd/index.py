@@ -61,12 +61,93 @@ class DenseUnitigTable:  # src/index/dense_unitig_table.rs:12-76 (U2Pos)
     def encoded_unitig_occs(self, ui):
         return self.ctable[int(self.contig_offsets[ui]): int(self.contig_offsets[ui + 1])]
 
+    def decode_occs(self, idx):
+        """(ref_id, pos, forward?) of the occurrences at table indices idx"""
+        return self.decode_pf1(self.ctable[idx])
+
+    def decode_unitig_occs(self, ui):  # dense_unitig_table.rs:65-67
+        return self.decode_pf1(self.encoded_unitig_occs(ui))
+
     @staticmethod
     def decode_pf1(words):  # UnitigOcc::decode_pf1, src/index.rs:334-346
         words = np.asarray(words, dtype=np.uint64)
         ref_id = words & np.uint64(0xFFFFFFFF)
         pw = words >> np.uint64(32)
         return ref_id, pw & np.uint64(0x7FFFFFFF), (pw & np.uint64(0x80000000)) != 0
+
+
+def _pack(values, width):
+    """IntVector with `width` bits per element (element i at bit i * width, first element in the low bits) as uint64 words"""
+    values = np.asarray(values, dtype=np.uint64)
+    n = len(values)
+    words = np.zeros((n * width + 63) // 64 + 1, dtype=np.uint64)
+    bit = np.arange(n, dtype=np.uint64) * np.uint64(width)
+    wi, sh = (bit >> np.uint64(6)).astype(np.int64), bit & np.uint64(63)
+    np.bitwise_or.at(words, wi, values << sh)
+    spill = (sh + np.uint64(width)) > np.uint64(64)
+    np.bitwise_or.at(words, wi[spill] + 1, values[spill] >> (np.uint64(64) - sh[spill]))
+    return words[: (n * width + 63) // 64] if n else words[:0]
+
+
+def _unpack(words, idx, width):
+    idx = np.asarray(idx, dtype=np.uint64)
+    w = np.concatenate([np.asarray(words, dtype=np.uint64), np.zeros(2, dtype=np.uint64)])
+    bit = idx * np.uint64(width)
+    wi, sh = (bit >> np.uint64(6)).astype(np.int64), bit & np.uint64(63)
+    x = (w[wi] >> sh) | np.where(sh > 0, w[wi + 1] << ((np.uint64(64) - sh) & np.uint64(63)), np.uint64(0))
+    return x if width == 64 else x & np.uint64((1 << width) - 1)
+
+
+def _bit_width(n):
+    return max(1, int(n).bit_length())
+
+
+class PiscemUnitigTable:  # src/index/dense_unitig_table.rs:110-153 (U2Pos over occurrences packed into the minimal number of bits)
+    def __init__(self, ctable_words, n_occs, occ_width, ref_shift, pos_mask, contig_offsets, ref_names):
+        self.ctable_words = np.ascontiguousarray(ctable_words, dtype=np.uint64)
+        self.n_occs, self.occ_width, self.ref_shift, self.pos_mask = int(n_occs), int(occ_width), int(ref_shift), int(pos_mask)
+        self.contig_offsets = np.ascontiguousarray(contig_offsets, dtype=np.uint64)  # plain copy for the host mirror
+        self.offsets_width = _bit_width(int(self.contig_offsets.max()) if len(self.contig_offsets) else 0)  # IntVector::pack, piscem_index.rs:30-31
+        self.contig_offsets_words = _pack(self.contig_offsets, self.offsets_width)
+        self.ref_names = list(ref_names)
+        self._h = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.mz_u2pos_free(self._h)
+            self._h = None
+
+    @classmethod
+    def from_occs(cls, ref_id, pos, fwd, contig_offsets, ref_names, max_ref_len):
+        """TileOccTable::from_occ_info + set_occ (src/spt_compact.rs:132-160): widths from the longest reference and the
+        number of references (required_num_bits, :221-243), words by UnitigOcc::encode_piscem (:90-96)"""
+        pos_bits = int(max_ref_len).bit_length()          # ilog2(longest_ref) + 1
+        ref_bits = int(len(ref_names)).bit_length()        # ilog2(num_refs) + 1
+        width, ref_shift = 1 + pos_bits + ref_bits, pos_bits + 1
+        words = (np.asarray(ref_id, dtype=np.uint64) << np.uint64(ref_shift)) | (np.asarray(pos, dtype=np.uint64) << np.uint64(1)) | np.asarray(fwd, dtype=np.uint64)
+        return cls(_pack(words, width), len(words), width, ref_shift, (1 << pos_bits) - 1, contig_offsets, ref_names)
+
+    def handle(self):
+        if self._h is None:
+            h = C.c_void_p()
+            check(lib.mz_u2pos_piscem_new(self.ctable_words.ctypes.data, self.n_occs, self.occ_width, self.ref_shift, self.pos_mask,
+                                          self.contig_offsets_words.ctypes.data, self.offsets_width, len(self.contig_offsets) - 1, C.byref(h)))
+            self._h = h
+        return self._h
+
+    def n_unitig_occs(self, ui): return lib.mz_u2pos_n_unitig_occs(self.handle(), ui)
+    def num_total_occs(self): return lib.mz_u2pos_num_total_occs(self.handle())
+
+    def encoded_unitig_occs(self, ui):  # OccsRange, dense_unitig_table.rs:130-135
+        return range(int(self.contig_offsets[ui]), int(self.contig_offsets[ui + 1]))
+
+    def decode_occs(self, idx):  # UnitigOcc::decode_piscem, src/spt_compact.rs:97-112
+        e = _unpack(self.ctable_words, idx, self.occ_width)
+        return e >> np.uint64(self.ref_shift), (e >> np.uint64(1)) & np.uint64(self.pos_mask), (e & np.uint64(1)) != 0
+
+    def decode_unitig_occs(self, ui):  # dense_unitig_table.rs:137-144
+        r = self.encoded_unitig_occs(ui)
+        return self.decode_occs(np.arange(r.start, r.stop, dtype=np.uint64))
 
 
 class RefSeqCollection:  # src/refseq.rs:17-20
@@ -124,7 +205,7 @@ class ModIndex:  # src/index.rs:49-124
         rec = recs[0]
         if int(rec["match"]) == 0:
             return None
-        ref_id, cpos, fwd = DenseUnitigTable.decode_pf1(self.u2pos.encoded_unitig_occs(int(rec["unitig_id"])))
+        ref_id, cpos, fwd = self.u2pos.decode_unitig_occs(int(rec["unitig_id"]))
         return project_onto_u_occs(self.k(), rec, ref_id, cpos, fwd)
 
     def _validate_batch(self, fw_words, ref_id, ref_pos, k2u_batch):
@@ -141,7 +222,7 @@ class ModIndex:  # src/index.rs:49-124
         cnt = e - s
         owner = np.repeat(np.arange(len(recs)), cnt)
         idx = np.repeat(s, cnt) + (np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt))
-        orid, cpos, fwd = DenseUnitigTable.decode_pf1(self.u2pos.ctable[idx])
+        orid, cpos, fwd = self.u2pos.decode_occs(idx)
         upos, ulen = recs["pos"].astype(np.int64)[owner], recs["unitig_len"].astype(np.int64)[owner]
         pos = np.where(fwd, upos + cpos.astype(np.int64), cpos.astype(np.int64) + (ulen - upos) - k)
         ok = (pos == ref_pos.astype(np.int64)[owner]) & (orid.astype(np.int64) == ref_id)
@@ -305,14 +386,20 @@ class SPT:
         return RefSeqCollection(None, ps)
 
 
-def index_from_cf_prefix(prefix, k2u_factory):
+def index_from_cf_prefix(prefix, k2u_factory, piscem=False):
     """PufferfishDenseIndexDefault::from_cf_prefix (src/index/defaults.rs:16-54) with the K2U slot filled by
-    `k2u_factory(seqs, k)` -- e.g. a GPU SSHash, which makes it the PiscemIndexDefault composition over the
-    dense occurrence table."""
+    `k2u_factory(seqs, k)` -- e.g. a GPU SSHash; piscem=True gives PiscemIndex::from_cf_prefix instead
+    (src/index/piscem_index.rs:17-56): same tiling, occurrences packed into the minimal number of bits
+    (SPTCompact, src/spt_compact.rs:287-389) behind a PiscemUnitigTable."""
     spt = SPT.from_cf_prefix(prefix)
     k2u = k2u_factory(spt.seqs, spt.k())
-    return ModIndex.from_parts({"index_type": "PufferfishDense"}, k2u, DenseUnitigTable(spt.ctable, spt.offsets, spt.ref_names),
-                               spt.get_ref_seq_collection()), spt
+    if piscem:
+        ref_id, pos, fwd = DenseUnitigTable.decode_pf1(spt.ctable)
+        u2pos = PiscemUnitigTable.from_occs(ref_id, pos, fwd, spt.offsets, spt.ref_names, int(max(spt.ref_lens)) if len(spt.ref_lens) else 0)
+        base = {"index_type": "Piscem"}
+    else:
+        u2pos, base = DenseUnitigTable(spt.ctable, spt.offsets, spt.ref_names), {"index_type": "PufferfishDense"}
+    return ModIndex.from_parts(base, k2u, u2pos, spt.get_ref_seq_collection()), spt
 
 
 def validate_fasta_on_device(index, path):

@@ -161,3 +161,50 @@ def test_index_from_cuttlefish_prefix_validate_fasta(name, w, skew):  # defaults
     st = idx.as_streaming()                                       # .as_streaming().validate_fasta with the host projection
     n_host = sum(st.validate_ckmers(ri, seq) for ri, (_, seq) in enumerate(recs))
     assert n_dev == n_host and n_dev > 0
+
+
+def test_piscem_occurrence_codec_known_answers():  # spt_compact.rs:504-520 (occ_encoding), :398-404 (masks), :407-430 (compare_spt_impls)
+    t = I.PiscemUnitigTable.from_occs([0], [1], [False], [0, 1], ["r"], max_ref_len=2)   # ref_shift 3 -> word 0b010
+    assert (t.ref_shift, t.pos_mask) == (3, 0b11)
+    assert int(I._unpack(t.ctable_words, [0], t.occ_width)[0]) == 0b010
+    r, p_, f = t.decode_occs(np.array([0]))
+    assert (int(r[0]), int(p_[0]), bool(f[0])) == (0, 1, False)
+    for i in range(1, 64):  # POS_MASKS[i] has bit width i
+        assert I._bit_width((1 << i) - 1) == i
+    for name in ("tiny", "yeast_chr7"):  # the compact table decodes to the very occurrences of the 64-bit table
+        spt = I.SPT.from_cf_prefix(os.path.join(H.GOLDEN, "cf", name, name))
+        rid, pos, fwd = I.DenseUnitigTable.decode_pf1(spt.ctable)
+        t = I.PiscemUnitigTable.from_occs(rid, pos, fwd, spt.offsets, spt.ref_names, int(max(spt.ref_lens)))
+        assert t.occ_width == 1 + int(max(spt.ref_lens)).bit_length() + len(spt.ref_names).bit_length() and t.occ_width < 64
+        r2, p2, f2 = t.decode_occs(np.arange(len(spt.ctable)))
+        assert np.array_equal(r2, rid) and np.array_equal(p2, pos) and np.array_equal(f2, fwd)
+        assert np.array_equal(I._unpack(t.contig_offsets_words, np.arange(len(spt.offsets)), t.offsets_width), spt.offsets)
+    spt = I.SPT.from_cf_prefix(os.path.join(H.GOLDEN, "cf", "tiny", "tiny"))   # spt_compact.rs:432-500 through the compact table
+    rid, pos, fwd = I.DenseUnitigTable.decode_pf1(spt.ctable)
+    t = I.PiscemUnitigTable.from_occs(rid, pos, fwd, spt.offsets, spt.ref_names, int(max(spt.ref_lens)))
+    got = [tuple(int(x[0]) if j < 2 else bool(x[0]) for j, x in enumerate(t.decode_occs(np.array([i])))) for i in range(4)]
+    assert got == [(0, 3, True), (1, 11, False), (0, 14, False), (1, 0, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,skew", [("tiny", 3, 2), ("yeast_chr7", 15, 32)])
+def test_piscem_index_validate_fasta_and_projection_parity(name, w, skew):  # piscem_index.rs:63-99, dense_unitig_table.rs:127-153
+    """PiscemIndex::from_cf_prefix with the occurrences packed into the minimal number of bits: validate_fasta with lookup,
+    projection and assertion on the GPU (plain and through .as_streaming()), and record-for-record the same MappedRefPos
+    lists as the 64-bit DenseUnitigTable"""
+    prefix = os.path.join(H.GOLDEN, "cf", name, name)
+    factory = lambda seqs, k: M.SSHash.from_unitig_set_on_device(M.UnitigSet.from_seqs(seqs, k), w, skew)  # noqa: E731
+    pidx, spt = I.index_from_cf_prefix(prefix, factory, piscem=True)
+    didx, _ = I.index_from_cf_prefix(prefix, factory)
+    assert pidx.u2pos.occ_width < 64 and pidx.u2pos.num_total_occs() == spt.n_total_occs() == didx.u2pos.num_total_occs()
+    assert [pidx.u2pos.n_unitig_occs(u) for u in range(min(50, spt.n_unitigs()))] == [didx.u2pos.n_unitig_occs(u) for u in range(min(50, spt.n_unitigs()))]
+    recs = H.read_fasta(prefix + ".fa")
+    n_dev = I.validate_fasta_on_device(pidx, prefix + ".fa")
+    st = pidx.as_streaming()
+    assert n_dev == sum(st.validate_ckmers(ri, seq) for ri, (_, seq) in enumerate(recs)) and n_dev > 0
+    rng = np.random.default_rng(3)
+    words, total, starts = H.pack_seqs(spt.seqs)
+    fw = np.concatenate([H.query_mix(words, starts, spt.k(), 20_000, seed=8), rng.integers(0, 1 << (2 * spt.k()), 500, dtype=np.uint64)])
+    po, pr = pidx.get_ref_pos_batch(fw)
+    do, dr = didx.get_ref_pos_batch(fw)
+    assert po.tobytes() == do.tobytes() and pr.tobytes() == dr.tobytes() and len(pr) > 5_000
