@@ -63,6 +63,10 @@ struct DevBuf { // frees everything it allocated when it goes out of scope
     void release(void *p) {
         for (auto &q : ptrs) if (q == p) { (void)hipFree(p); q = nullptr; }
     }
+    // hand a buffer over to `d` (it is no longer freed here)
+    void give(void *p, DeviceIndex *d, uint64_t bytes) {
+        for (auto &q : ptrs) if (q == p) { q = nullptr; d->allocs.push_back(p); d->bytes += bytes; return; }
+    }
 };
 
 struct ScanParams {
@@ -398,7 +402,11 @@ bool gpu_build_supported(const UnitigSet &us, uint32_t w) {
 }
 
 // returns MZ_OK and fills `h` like SSHashHost::build, or MZ_EINVAL with last_error "unsupported" (caller falls back)
-int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device) {
+int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device, DeviceIndex **keep) {
+    // keep != nullptr: the finished arrays stay in HBM as the replica *keep and are NOT copied to the host (h.arrays_on_host
+    // == false; device_download() brings them over when somebody needs them there)
+    if (keep) *keep = nullptr;
+    const bool resident = keep != nullptr;
     const double t_begin = now_s();
     const bool timing = std::getenv("MZ_BUILD_TIMING") != nullptr;
     double tp = t_begin;
@@ -492,6 +500,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
     if (timing) std::fprintf(stderr, "[mz gpu build] %llu of %llu minimizer records overflow to the global offsets\n", (unsigned long long)h.n_minrec_overflow, (unsigned long long)n_rec);
 
     // global partitioned Elias-Fano over psum
+    uint64_t *d_bef_blocks = nullptr, *d_bef_ovf = nullptr, *d_packed_keep = nullptr, *d_lines_keep = nullptr, *d_minrec_keep = nullptr;
     {
         const uint64_t n = n_mm + 1, nb = ((n - 1) >> kBefShift) + 1;
         uint64_t *d_blocks = nullptr, *d_flag = nullptr, *d_rank = nullptr;
@@ -504,17 +513,19 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         uint64_t n_ov = 0;
         BG_HIP(hipMemcpy(&n_ov, d_rank + nb, 8, hipMemcpyDeviceToHost));
         h.buckets.n = n; h.buckets.n_overflow = n_ov;
+        BG_HIP(buf.alloc(&d_bef_ovf, n_ov ? n_ov * (kBefSpan + 1) : 2));
         if (n_ov) {
-            uint64_t *d_ovf = nullptr;
-            BG_HIP(buf.alloc(&d_ovf, n_ov * (kBefSpan + 1)));
-            hipLaunchKernelGGL(bef_overflow_kernel, dim3(grid_of(nb)), dim3(kB), 0, 0, d_psum, n, nb, d_flag, d_rank, d_blocks, d_ovf);
-            if (int rc = download(h.buckets.ovf, d_ovf, n_ov * (kBefSpan + 1))) return rc;
-            buf.release(d_ovf);
+            hipLaunchKernelGGL(bef_overflow_kernel, dim3(grid_of(nb)), dim3(kB), 0, 0, d_psum, n, nb, d_flag, d_rank, d_blocks, d_bef_ovf);
         } else {
-            h.buckets.ovf.assign(2, 0);
+            BG_HIP(hipMemset(d_bef_ovf, 0, 16));
         }
-        if (int rc = download(h.buckets.blocks, d_blocks, nb * 8)) return rc;
-        buf.release(d_blocks); buf.release(d_flag); buf.release(d_rank);
+        d_bef_blocks = d_blocks;
+        if (!resident) {
+            if (int rc = download(h.buckets.ovf, d_bef_ovf, n_ov ? n_ov * (kBefSpan + 1) : 2)) return rc;
+            if (int rc = download(h.buckets.blocks, d_blocks, nb * 8)) return rc;
+            buf.release(d_blocks); buf.release(d_bef_ovf);
+        }
+        buf.release(d_flag); buf.release(d_rank);
     }
     // packed pos entries
     {
@@ -525,8 +536,10 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         BG_HIP(buf.alloc(&d_packed, n_words));
         hipLaunchKernelGGL(pos_entries_kernel, dim3(grid_of(n_words)), dim3(kB), 0, 0, d_keys, n_occ, P, h.pos.width, n_words, d_packed);
         hipLaunchKernelGGL(record_filters_kernel, dim3(grid_of(n_mm)), dim3(kB), 0, 0, d_minrec, d_mm, n_mm, d_psum, d_packed, skew_param);
-        if (int rc = download(h.pos.w, d_packed, n_words)) return rc;
-        if (int rc = download(h.mm.blocks, d_minrec, n_rec * kMinRecWords)) return rc;
+        if (!resident) {
+            if (int rc = download(h.pos.w, d_packed, n_words)) return rc;
+            if (int rc = download(h.mm.blocks, d_minrec, n_rec * kMinRecWords)) return rc;
+        }
         // minimizer lines from the finished records, bucket starts and entries
         const int fg = FrontTable::choose_g(w, n_occ, true);
         h.front.present = fg >= 0;
@@ -538,15 +551,23 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
             BG_HIP(buf.alloc(&d_lines, n_lines * kFrontSlots));
             hipLaunchKernelGGL(front_lines_kernel, dim3(grid_of(n_lines)), dim3(kB), 0, 0, d_minrec, (uint32_t)fg, n_lines, d_psum, d_packed, skew_param, d_lines);
             BG_HIP(hipGetLastError());
-            if (int rc = download(h.front.lines, d_lines, n_lines * kFrontSlots)) return rc;
-            buf.release(d_lines);
+            if (!resident) {
+                if (int rc = download(h.front.lines, d_lines, n_lines * kFrontSlots)) return rc;
+                buf.release(d_lines);
+            }
+            d_lines_keep = d_lines;
         }
-        buf.release(d_packed);
-        buf.release(d_minrec);
+        d_packed_keep = d_packed;
+        d_minrec_keep = d_minrec;
+        if (!resident) {
+            buf.release(d_packed);
+            buf.release(d_minrec);
+        }
     }
     phase("G3 offsets + entries + lines");
 
     // ---- G4: skew index
+    uint64_t *d_skew_tab = nullptr, *d_skew_ow = nullptr, *d_skew_op = nullptr;
     if (skew_param != ~0ull) {
         BG_HIP(hipMemset(d_counter, 0, 8));
         const unsigned kgrid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(n_mm, 1), 256 * 64);
@@ -596,21 +617,68 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
             ROCPRIM_RUN(buf, rocprim::select(tmp, tmp_bytes, d_ix2, d_ovflag, d_ix, d_nsel, sn)); // d_ix reused: overflowed key indices, in (bucket, word) order
             uint64_t n_ovf = 0;
             BG_HIP(hipMemcpy(&n_ovf, d_nsel, 8, hipMemcpyDeviceToHost));
+            st.n_ovf = n_ovf;
+            BG_HIP(buf.alloc(&d_skew_ow, n_ovf));
+            BG_HIP(buf.alloc(&d_skew_op, n_ovf));
             if (n_ovf) {
-                hipLaunchKernelGGL(gather_kernel, dim3(grid_of(n_ovf)), dim3(kB), 0, 0, d_tw2, d_ix, n_ovf, d_hb2);
-                hipLaunchKernelGGL(gather_kernel, dim3(grid_of(n_ovf)), dim3(kB), 0, 0, d_tp2, d_ix, n_ovf, d_first);
-                if (int rc = download(st.ovf_word, d_hb2, n_ovf)) return rc;
-                if (int rc = download(st.ovf_pos, d_first, n_ovf)) return rc;
+                hipLaunchKernelGGL(gather_kernel, dim3(grid_of(n_ovf)), dim3(kB), 0, 0, d_tw2, d_ix, n_ovf, d_skew_ow);
+                hipLaunchKernelGGL(gather_kernel, dim3(grid_of(n_ovf)), dim3(kB), 0, 0, d_tp2, d_ix, n_ovf, d_skew_op);
+                BG_HIP(hipGetLastError());
             }
-            if (int rc = download(st.buckets, d_tab, n_slots)) return rc;
+            d_skew_tab = d_tab;
+            if (!resident) {
+                if (n_ovf) {
+                    if (int rc = download(st.ovf_word, d_skew_ow, n_ovf)) return rc;
+                    if (int rc = download(st.ovf_pos, d_skew_op, n_ovf)) return rc;
+                }
+                if (int rc = download(st.buckets, d_tab, n_slots)) return rc;
+            }
         } else {
-            st.buckets.assign(n_slots, kSkewEmpty);
+            st.n_ovf = 0;
+            BG_HIP(buf.alloc(&d_skew_tab, n_slots));
+            BG_HIP(hipMemset(d_skew_tab, 0xFF, n_slots * 8));
+            BG_HIP(buf.alloc(&d_skew_ow, 0));
+            BG_HIP(buf.alloc(&d_skew_op, 0));
+            if (!resident) st.buckets.assign(n_slots, kSkewEmpty);
         }
         h.has_skew = true;
         phase("G4 skew table");
     }
     BG_HIP(hipDeviceSynchronize());
     BG_HIP(hipGetLastError());
+    h.arrays_on_host = !resident;
+    if (resident) { // the finished arrays become the replica of this device
+        h.mm.blocks.clear(); h.buckets.blocks.clear(); h.buckets.ovf.clear(); h.pos.w.clear();
+        h.skew.buckets.clear(); h.skew.ovf_word.clear(); h.skew.ovf_pos.clear();
+        uint64_t *d_starts = nullptr;
+        BG_HIP(buf.alloc(&d_starts, us.starts.size()));
+        BG_HIP(hipMemcpy(d_starts, us.starts.data(), us.starts.size() * 8, hipMemcpyHostToDevice));
+        DeviceIndex *d = new DeviceIndex();
+        d->device = device;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) d->n_cu = (uint32_t)prop.multiProcessorCount;
+        IndexView v = h.view();
+        v.seqbv = d_seqbv;                 buf.give(d_seqbv, d, us.seqbv.size() * 8);
+        v.starts = d_starts;               buf.give(d_starts, d, us.starts.size() * 8);
+        v.mm.blocks = d_minrec_keep;       buf.give(d_minrec_keep, d, h.n_mm_block_words() * 8);
+        v.mm.levels = nullptr;
+        v.buckets.blocks = d_bef_blocks;   buf.give(d_bef_blocks, d, h.n_bucket_block_words() * 8);
+        v.buckets.ovf = d_bef_ovf;         buf.give(d_bef_ovf, d, h.n_bucket_ovf_words() * 8);
+        v.pos = d_packed_keep;             buf.give(d_packed_keep, d, (h.pos.n + 2) * 8);
+        if (h.has_skew) {
+            v.skew = h.skew.view();
+            v.skew.buckets = d_skew_tab;   buf.give(d_skew_tab, d, h.skew.n_slots() * 8);
+            v.skew.ovf_word = d_skew_ow;   buf.give(d_skew_ow, d, h.skew.n_ovf * 8);
+            v.skew.ovf_pos = d_skew_op;    buf.give(d_skew_op, d, h.skew.n_ovf * 8);
+        }
+        v.front = h.front.view();
+        if (h.front.present) {
+            v.front = FrontView{d_lines_keep, (uint64_t)1 << (2 * w - h.front.g), h.front.g, 0};
+            buf.give(d_lines_keep, d, h.front.n_words(w) * 8);
+        }
+        d->view = v;
+        *keep = d;
+    }
     h.build_seconds = now_s() - t_begin;
     return MZ_OK;
 }

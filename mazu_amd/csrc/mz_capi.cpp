@@ -71,12 +71,20 @@ struct mz_streaming {
     } while (0)
 
 // replica on `device`, uploaded on first use; *out is owned by the handle
+// arrays of a GPU-built index live in HBM only until the host needs them (save, a replica on another GPU); caller holds ix->mu
+static int host_arrays(mz_sshash *ix) {
+    if (ix->host.arrays_on_host) return MZ_OK;
+    if (ix->replicas.empty()) { set_error("index arrays are neither on the host nor on a device"); return MZ_EINVAL; }
+    return device_download(*ix->replicas.front(), ix->host);
+}
 static int replica_on(mz_sshash *ix, int device, DeviceIndex **out) {
     std::lock_guard<std::mutex> g(ix->mu);
     for (DeviceIndex *r : ix->replicas)
         if (r->device == device) { *out = r; return MZ_OK; }
     DeviceIndex *nd = nullptr;
-    int rc = device_upload(ix->host, device, &nd);
+    int rc = host_arrays(ix);
+    if (rc != MZ_OK) return rc;
+    rc = device_upload(ix->host, device, &nd);
     if (rc != MZ_OK) return rc;
     ix->replicas.push_back(nd);
     if (!ix->dev) ix->dev = nd;
@@ -167,7 +175,9 @@ int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64
     if (!ix) return MZ_ENOMEM;
     int rc = MZ_EINVAL;
     try {
-        if (gpu_build_supported(us->us, w)) rc = build_on_device(ix->host, us->us, w, skew_param, seed, device);
+        DeviceIndex *kept = nullptr; // the GPU builder leaves its arrays in HBM as the replica of `device`: no download, no second upload
+        if (gpu_build_supported(us->us, w)) rc = build_on_device(ix->host, us->us, w, skew_param, seed, device, &kept);
+        if (rc == MZ_OK && kept) { ix->replicas.push_back(kept); ix->dev = kept; }
         if (rc == MZ_ENOMEM) { // the device ran out of memory next to what already lives there: the host builder can still do it
             std::fprintf(stderr, "[mazu_amd] GPU index build ran out of device memory (%s); building on the host instead\n", last_error());
             ix->host = SSHashHost();
@@ -554,8 +564,15 @@ int mz_sshash_extract_kmers_device(mz_sshash *ix, const uint64_t *d_positions, c
     return launch_extract_kmers(*r, d_positions, d_flip, n, d_fw_words, (hipStream_t)stream);
 }
 
-int mz_sshash_save(const mz_sshash *ix, const char *path) {
-    if (!ix || !path) { set_error("null argument"); return MZ_EINVAL; }
+int mz_sshash_save(const mz_sshash *ix_, const char *path) {
+    if (!ix_ || !path) { set_error("null argument"); return MZ_EINVAL; }
+    mz_sshash *ix = const_cast<mz_sshash *>(ix_); // a GPU-built index fetches its arrays from HBM on first use (logically const)
+    DeviceGuard guard;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        int rc = host_arrays(ix);
+        if (rc != MZ_OK) return rc;
+    }
     return ix->host.save(path);
 }
 int mz_sshash_load(const char *path, mz_sshash **out) {

@@ -1194,6 +1194,28 @@ int device_upload(const SSHashHost &h, int device, DeviceIndex **out) {
     return MZ_OK;
 }
 
+int device_download(const DeviceIndex &d, SSHashHost &h) {
+    if (h.arrays_on_host) return MZ_OK;
+    MZ_HIP_CHECK(hipSetDevice(d.device));
+    auto get = [&](std::vector<uint64_t> &dst, const uint64_t *src, uint64_t n) -> hipError_t {
+        dst.resize(n);
+        return n ? hipMemcpy(dst.data(), src, n * 8, hipMemcpyDeviceToHost) : hipSuccess;
+    };
+    const IndexView &v = d.view;
+    MZ_HIP_CHECK(get(h.mm.blocks, v.mm.blocks, h.n_mm_block_words()));
+    MZ_HIP_CHECK(get(h.buckets.blocks, v.buckets.blocks, h.n_bucket_block_words()));
+    MZ_HIP_CHECK(get(h.buckets.ovf, v.buckets.ovf, h.n_bucket_ovf_words()));
+    MZ_HIP_CHECK(get(h.pos.w, v.pos, h.pos.n + 2));
+    if (h.has_skew) {
+        MZ_HIP_CHECK(get(h.skew.buckets, v.skew.buckets, h.skew.n_slots()));
+        MZ_HIP_CHECK(get(h.skew.ovf_word, v.skew.ovf_word, h.skew.n_ovf));
+        MZ_HIP_CHECK(get(h.skew.ovf_pos, v.skew.ovf_pos, h.skew.n_ovf));
+    }
+    if (h.front.present) MZ_HIP_CHECK(get(h.front.lines, v.front.lines, h.front.n_words(h.w)));
+    h.arrays_on_host = true;
+    return MZ_OK;
+}
+
 void device_free(DeviceIndex *d) {
     if (!d) return;
     if (d->device >= 0) (void)hipSetDevice(d->device);

@@ -48,7 +48,10 @@ int launch_extract_kmers(const DeviceIndex &d, const uint64_t *d_positions, cons
 
 // index construction on the device (mz_build_gpu.hip); false / MZ_EINVAL when the configuration needs the host builder
 bool gpu_build_supported(const UnitigSet &us, uint32_t w);
-int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device);
+// keep != nullptr: the arrays stay in HBM as the replica *keep and h.arrays_on_host is false (see device_download)
+int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device, DeviceIndex **keep = nullptr);
+// copies the index arrays of a replica into the (empty) host vectors of `h`; afterwards h.arrays_on_host is true
+int device_download(const DeviceIndex &d, SSHashHost &h);
 
 } // namespace mz
 

@@ -674,6 +674,7 @@ void SkewTable::build(const uint64_t *words, const uint64_t *pos, uint64_t n, in
     buckets.assign(std::max<uint64_t>(n_buckets * kSkewSlots, 2), kSkewEmpty);
     ovf_word.clear();
     ovf_pos.clear();
+    n_ovf = 0;
     if (n == 0) return;
     // (home bucket, index) pairs in increasing order: inside a bucket the keys keep their word order
     std::vector<Occ> by(n);
@@ -702,6 +703,7 @@ void SkewTable::build(const uint64_t *words, const uint64_t *pos, uint64_t n, in
         if (rank < kSkewSlots) B[hb * kSkewSlots + rank] = skew_slot(fp, pos[i]);
         else { ovf_word.push_back(words[i]); ovf_pos.push_back(pos[i]); }
     }
+    n_ovf = ovf_word.size();
 }
 
 int FrontTable::choose_g(uint32_t w, uint64_t n_occ, bool direct) {
@@ -936,10 +938,11 @@ IndexView SSHashHost::view() const {
 }
 
 // sshash.rs:341-358 (the MPHF term is the exact size of ours, not a bincode estimate)
-uint64_t SSHashHost::num_bits() const {
-    uint64_t b = 64 + us.num_bits() + buckets.num_bits() + pos.num_bits() + mm.num_bits();
+uint64_t SSHashHost::num_bits() const { // from the scalars: the arrays may still be in HBM only
+    uint64_t b = 64 + us.num_bits() + 64 * (n_bucket_block_words() + n_bucket_ovf_words()) + pos.num_bits() +
+                 64 * n_mm_block_words() + mm.levels.size() * sizeof(MphfLevel) * 8;
     if (has_skew) b += skew.num_bits();
-    return b + front.num_bits();
+    return b + 64 * front.n_words(w);
 }
 
 // ------------------------------------------------------------------ flat file
@@ -974,6 +977,10 @@ static void put_pv(std::ofstream &f, const PackedVec &p) { put(f, p.n); put(f, p
 static bool get_pv(std::ifstream &f, PackedVec &p) { return get(f, p.n) && get(f, p.width) && getv(f, p.w); }
 
 int SSHashHost::save(const std::string &path) const {
+    if (!arrays_on_host) {
+        set_error("index arrays are resident in HBM only; bring them to the host first");
+        return MZ_EINVAL;
+    }
     std::ofstream f(path, std::ios::binary);
     if (!f) {
         set_error("cannot create %s", path.c_str());
@@ -1083,6 +1090,8 @@ int SSHashHost::load(const std::string &path) {
         set_error("%s: truncated", path.c_str());
         return MZ_EIO;
     }
+    skew.n_ovf = has_skew ? skew.ovf_word.size() : 0;
+    arrays_on_host = true;
     if (const char *what = check_loaded(*this)) {
         set_error("%s: inconsistent index file (%s)", path.c_str(), what);
         return MZ_EIO;

@@ -95,12 +95,13 @@ private:
 // with their positions; the result depends only on that set (the GPU builder produces the same arrays).
 struct SkewTable {
     std::vector<uint64_t> buckets, ovf_word, ovf_pos;
-    uint64_t n_buckets = 0, n_keys = 0;
+    uint64_t n_buckets = 0, n_keys = 0, n_ovf = 0; // n_ovf == ovf_word.size() whenever the arrays are on the host
     uint32_t fp_bits = kSkewFpBits; // fingerprint width of a slot
     uint32_t fp_mask() const { return (uint32_t)((1ull << fp_bits) - 1); }
     void build(const uint64_t *words, const uint64_t *pos, uint64_t n, int n_threads);
-    SkewView view() const { return SkewView{buckets.data(), ovf_word.data(), ovf_pos.data(), n_buckets, (uint64_t)ovf_word.size(), n_keys, fp_mask(), 0}; }
-    uint64_t num_bits() const { return 64 * (uint64_t)(buckets.size() + ovf_word.size() + ovf_pos.size()); }
+    SkewView view() const { return SkewView{buckets.data(), ovf_word.data(), ovf_pos.data(), n_buckets, n_ovf, n_keys, fp_mask(), 0}; }
+    uint64_t n_slots() const { return n_buckets * kSkewSlots > 2 ? n_buckets * kSkewSlots : 2; }
+    uint64_t num_bits() const { return 64 * (n_slots() + 2 * n_ovf); }
 };
 
 // Minimizer lines (layout: FrontView in mz_common.hpp).  Built from the minimizer records, the bucket starts and the
@@ -113,7 +114,7 @@ struct FrontTable {
     static int choose_g(uint32_t w, uint64_t n_occ, bool direct);
     void build(const uint64_t *minrec, uint32_t w, int g_, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads);
     FrontView view() const { return present ? FrontView{lines.data(), (uint64_t)lines.size() / kFrontSlots, g, 0} : FrontView{nullptr, 0, 0, 0}; }
-    uint64_t num_bits() const { return present ? 64ull * lines.size() : 0; }
+    uint64_t n_words(uint32_t w) const { return present ? (1ull << (2 * w - g)) * kFrontSlots : 0; }
 };
 
 struct SSHashHost {
@@ -129,6 +130,13 @@ struct SSHashHost {
     FrontTable front; // minimizer lines (optional)
     uint64_t n_minimizers = 0, n_minrec_overflow = 0;
     double build_seconds = 0;
+    // false after a GPU build that left its arrays in HBM (mm.blocks, buckets, pos.w, skew and front vectors are then empty
+    // until somebody needs them on the host: save(), a replica on another GPU); the scalars and `us` are always here
+    bool arrays_on_host = true;
+    // sizes of the arrays above in words, from the scalars alone
+    uint64_t n_mm_block_words() const { return mm.direct ? ((((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords) : (uint64_t)mm.blocks.size(); }
+    uint64_t n_bucket_block_words() const { return (((buckets.n - 1) >> kBefShift) + 1) * 8; }
+    uint64_t n_bucket_ovf_words() const { return buckets.n_overflow ? buckets.n_overflow * (kBefSpan + 1) : 2; }
 
     int build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads);
     IndexView view() const;
