@@ -109,7 +109,7 @@ constexpr int kStopAfter = MZ_STOP_AFTER;
 #define MZ_WAVES_PER_EU 4
 #endif
 #ifndef MZ_READS_WAVES
-#define MZ_READS_WAVES 2 // minimum waves per SIMD the reads kernel is compiled for: 2 leaves the register allocator at ~160 VGPRs = 3 waves, measured best (3 -> 146 VGPRs: -3 %, unbounded -> 169 VGPRs = 2 waves: -22 %)
+#define MZ_READS_WAVES 3 // minimum waves per SIMD the reads kernel is compiled for (<= 168 VGPRs; at 2 the allocator takes 179 and the kernel runs 20 % slower)
 #endif
 constexpr int kRecBatch = MZ_REC_BATCH; // minimizer records in flight per lane (S1)
 // S.n[i]: bucket size (< kNSkew), or one of the markers below (kNIdle: no query in this slot)
@@ -117,7 +117,7 @@ constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFF
 // S.qinfo[i]: the flank16 an entry must show for item i (mz_common.hpp `pos` entry), in the orientation of the canonical
 // word g*: bits 0..7 = the 4 bases left of the minimizer in g*, bits 8..15 = the 4 bases right of it | offset << 16 |
 // kQMulti once a second bucket entry survived the flank filter
-constexpr uint32_t kQOffShift = 16, kQOffMask = 0x1Fu, kQMulti = 0x80000000u, kQIdle = 0x40000000u; // kQIdle: no query in this slot
+constexpr uint32_t kQOffShift = 16, kQOffMask = 0x1Fu, kQMulti = 0x80000000u, kQIdle = 0x40000000u, kQClass = 1u << 21; // kQClass: the canonical k-mer is the reverse strand; // kQIdle: no query in this slot
 __device__ __forceinline__ uint32_t query_flank(uint64_t g, uint32_t off, uint32_t w) {
     const uint32_t ql = (uint32_t)(off >= kFlankBases ? g >> (2 * (off - kFlankBases)) : g << (2 * (kFlankBases - off))) & 0xFFu;
     const uint32_t qr = (uint32_t)(g >> (2 * (off + w))) & 0xFFu;
@@ -321,7 +321,7 @@ __device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, 
                                                bool lines) {
     const uint32_t fl = query_flank(fw <= rc ? fw : rc, mn.offset, w);
     S.fw[i] = fw;
-    S.qinfo[i] = fl | (mn.offset << kQOffShift) | (valid ? 0u : kQIdle);
+    S.qinfo[i] = fl | (mn.offset << kQOffShift) | (valid ? 0u : kQIdle) | (fw <= rc ? 0u : kQClass);
     S.best[i] = kBestNone;
     S.n[i] = valid ? 0u : kNIdle;
     if (lines) {
@@ -333,7 +333,9 @@ __device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, 
     }
 }
 
-template <class SC>
+// kRuns: consecutive items of the tile tend to carry the same minimizer (the windows of a read): the direct-address stage then
+// reads one record per RUN of equal keys instead of one per item
+template <class SC, bool kRuns = false>
 __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexView &ix) {
     const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
     SC::sync();
@@ -414,7 +416,103 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     } else
     // ---- S1: minimizer -> bucket id.  Direct-address rank bitmap (2w <= 32): one dense gather, no rounds;
     //          otherwise the BBHash level loop
-    if (ix.mm.direct) {
+    if (kRuns && SC::NT == 64) {
+        // S1+S2 once per run of equal keys.  Items are numbered along the read (item q * 64 + lane).  The windows whose canonical
+        // k-mer is the forward strand keep their minimizer for a stretch of positions, and so do those whose canonical k-mer is
+        // the reverse strand, but the two strands interleave at random: an item belongs to the run of the nearest earlier item of
+        // ITS strand class when the keys agree, else it leads a new run.  Leaders go into a dense list and are resolved by full
+        // waves (record decode or MPHF levels + bucket offsets); the other items copy the bucket range of their leader.
+        // The negative filter of a minimizer record is per query and is skipped here: S3 / S5 reject the same items, later.
+        const uint32_t lane = t;
+        const unsigned long long le_mask = ~0ull >> (63 - lane), lt_mask = le_mask >> 1;
+        uint32_t leader_of[kQpt];                                   // item that leads my run (myself for a leader)
+        uint32_t n_runs = 0, follows = 0;
+        uint32_t last_key0 = 0, last_key1 = 0, last_ldr0 = ~0u, last_ldr1 = ~0u; // per strand class: key of its latest item and that item's leader (uniform)
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            const uint32_t i = q * 64 + lane, qi = S.qinfo[i];
+            const bool act = !(qi & kQIdle), cls = (qi & kQClass) != 0;
+            const uint64_t key = S.slot[i];
+            const unsigned long long act_b = __ballot(act), cls_b = __ballot(cls);
+            const unsigned long long mine_b = (cls ? cls_b : ~cls_b) & act_b;       // active items of my class in this row
+            const unsigned long long before = mine_b & lt_mask;
+            const uint32_t src = before ? 63u - (uint32_t)__clzll(before) : lane;   // nearest earlier one
+            const uint64_t pk = (uint64_t)__shfl((unsigned long long)key, (int)src);
+            const uint32_t carried = cls ? last_ldr1 : last_ldr0;
+            const bool first_of_class = before == 0;
+            const bool lead = act && (first_of_class ? carried == ~0u || (uint32_t)key != (cls ? last_key1 : last_key0) || (key >> 32) != 0 : key != pk);
+            const unsigned long long lead_b = __ballot(lead);
+            const unsigned long long lead_mine = lead_b & mine_b & le_mask;         // leaders of my class at or before me in this row
+            leader_of[q] = lead_mine ? q * 64 + 63u - (uint32_t)__clzll(lead_mine) : carried;
+            if (lead) S.eoff[n_runs + (uint32_t)__popcll(lead_b & lt_mask)] = i;
+            if (act && !lead) follows |= 1u << q;
+            if (const unsigned long long cb = ~cls_b & act_b) { // carry each class's latest item over to the next row
+                const int lastl = 63 - __clzll(cb);
+                last_key0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, lastl);
+                last_ldr0 = (uint32_t)__builtin_amdgcn_readlane((int)leader_of[q], lastl);
+            }
+            if (const unsigned long long cb = cls_b & act_b) {
+                const int lastl = 63 - __clzll(cb);
+                last_key1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, lastl);
+                last_ldr1 = (uint32_t)__builtin_amdgcn_readlane((int)leader_of[q], lastl);
+            }
+            n_runs += (uint32_t)__popcll(lead_b);
+        }
+        SC::sync();
+        if (ix.mm.direct) {
+            for (uint32_t base = 0; base < n_runs; base += 64) {
+                const bool have = base + lane < n_runs;
+                const uint32_t i = have ? S.eoff[base + lane] : 0u;
+                const uint32_t key = have ? (uint32_t)S.slot[i] : 0u;
+                const uint64_t *rec = ix.mm.blocks + (uint64_t)(key >> kMinRecKeysLog2) * kMinRecWords;
+                const ulonglong2 pr = *reinterpret_cast<const ulonglong2 *>(rec + 2 * ((key & ((1u << kMinRecKeysLog2) - 1)) >> 6));
+                uint64_t L[8];
+                const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(rec + 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const ulonglong2 x = v[j]; L[2 * j] = x.x; L[2 * j + 1] = x.y; }
+                uint32_t local;
+                const bool member = minrec_probe(pr.x, pr.y, key, local);
+                uint64_t ps = 0, pe = 0;
+                const bool ok = bef_decode_pair(L, local < kBefSpan ? local : 0u, nullptr, ps, pe) && local < kBefSpan;
+                if (have && member && !ok) bef_get_pair(ix.buckets, (pr.x & kMinRecRankMask) + local, ps, pe); // the record defers to the global offsets (rare)
+                const uint64_t cnt = pe - ps;
+                if (have) {
+                    S.slot[i] = ps;
+                    S.n[i] = !member ? kNMiss : cnt > ix.skew_param ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
+                }
+            }
+        } else {
+            for (uint32_t j = lane; j < n_runs; j += 64) S.list_a[j] = (typename TileLdsT<SC::NT>::ListT)S.eoff[j];
+            if (lane == 0) S.cnt_a = n_runs;
+            tile_mphf<SC>(S, ix.mm, false);
+            for (uint32_t j = lane; j < n_runs; j += 64) {
+                const uint32_t i = S.eoff[j];
+                if (S.n[i] < kNIdle) {
+                    uint64_t ps, pe;
+                    bef_get_pair(ix.buckets, S.slot[i], ps, pe);
+                    const uint64_t cnt = pe - ps;
+                    S.slot[i] = ps;
+                    S.n[i] = cnt > ix.skew_param ? kNSkew : (uint32_t)(cnt < 0x7FFFFFFFull ? cnt : 0x7FFFFFFFull);
+                }
+            }
+        }
+        SC::sync();
+        uint64_t cps[kQpt];
+        uint32_t cn[kQpt];
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) { // (reads first: a leader's words are another item's source)
+            const uint32_t li = (follows >> q) & 1u ? leader_of[q] : q * 64 + lane;
+            cps[q] = S.slot[li];
+            cn[q] = S.n[li];
+        }
+        SC::sync();
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            const uint32_t i = q * 64 + lane;
+            if ((follows >> q) & 1u) { S.slot[i] = cps[q]; S.n[i] = cn[q]; }
+            wave_push(S.list_b, &S.cnt_skew, cn[q] == kNSkew, i);
+        }
+    } else if (ix.mm.direct) {
         // S1+S2 fused: member test, bucket id and bucket range from ONE 128-byte minimizer record.  Straight-line and in
         // two batches so that the gathers of all kQpt items of a lane are in flight together: (a) the {header, bitmap word}
         // pair of the key, ONE 16-byte load, (b) the bucket-offset half of the same line.  Idle slots probe record 0 (always there).
@@ -873,12 +971,26 @@ __device__ __forceinline__ uint32_t base_code_dev(uint8_t c) {
 
 constexpr int kPlaneWords = kTileQ / 64 + 2; // plane words incl. the k-1 tail and a pad word
 
+constexpr int kReadsStaged = 64; // reads whose offsets are staged per tile (a tile that more reads touch takes the slow walk)
 template <typename H> // H = uint32_t when the w-mer hash has 32 significant bits (w <= 16), else uint64_t
 struct ReadsLds {
     uint64_t plane_lo[kPlaneWords], plane_hi[kPlaneWords], plane_inv[kPlaneWords];
-    H hf[kTileQ + 32], hr[kTileQ + 32]; // w-mer hashes of the tile, forward / reverse-complement strand
-    uint64_t read0;
+    uint64_t packed[kTileQ / 32 + 4];            // the tile's bases 2-bit packed (base i at bits [2i, 2i+1] of word i / 32), built from the planes
+    H hf[kTileQ + 32], hr[kTileQ + 32];          // w-mer hashes of the tile, forward / reverse-complement strand
+    uint64_t roff[kReadsStaged + 1];             // read_offsets[read0 + j]
+    uint64_t koff[kReadsStaged + 1];             // kmer_offsets[read0 + j]
+    uint64_t start_plane[kTileQ / 64];           // bit i: one of the staged reads 1.. starts at tile position i
+    uint32_t start_cum[kTileQ / 64];             // read starts in the plane words before this one
+    uint64_t read0;                              // read holding the first base of the tile
+    uint32_t slow;                               // != 0: more reads touch the tile than are staged (or a read is empty): walk read_offsets in global memory
 };
+// w- or k-mer starting at tile position i from the packed tile
+template <typename H>
+__device__ __forceinline__ uint64_t tile_mer(const ReadsLds<H> &R, uint32_t i, uint32_t len) {
+    const uint32_t wi = i >> 5, sh = 2 * (i & 31);
+    const uint64_t lo = R.packed[wi], hi = R.packed[wi + 1];
+    return ((lo >> sh) | ((hi << 1) << (63 - sh))) & kmer_mask(len);
+}
 
 // canonical minimizer of the window at tile position i from the staged w-mer hashes (== canonical_minimizer())
 template <typename H>
@@ -931,27 +1043,72 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     TileLdsT<SC::NT> &S = SS[wave];
     const uint64_t n_tiles = (n_bases + kTileQ - 1) / kTileQ;
+    // every workgroup takes a contiguous run of tiles, so the read that holds a tile's first base follows from the previous tile
+    const uint64_t tiles_per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint64_t tile_begin_wg = (uint64_t)blockIdx.x * tiles_per_wg, tile_end_wg = tile_begin_wg + tiles_per_wg < n_tiles ? tile_begin_wg + tiles_per_wg : n_tiles;
+    uint64_t next_read0 = ~0ull; // wave 0: read0 of the next tile when it is known, else ~0 (search)
     Tally tally;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (uint64_t tile = tile_begin_wg; tile < tile_end_wg; ++tile) {
         const uint64_t B0 = tile * kTileQ;
         tile_begin<SC>(S);
-        if (t == 0) { // read holding the first base of the tile: largest r with read_offsets[r] <= B0
-            uint64_t lo = 0, hi = n_reads;
-            while (hi - lo > 1) {
-                uint64_t mid = (lo + hi) >> 1;
-                if (read_offsets[mid] <= B0) lo = mid; else hi = mid;
-            }
-            R.read0 = lo;
-        }
         // stage the bit planes: kQpt x 256 positions (one ballot triple per wave and slice) + the k-1 tail
+        uint32_t code[kQpt];
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) { // the loads first: wave 0 looks the reads up while they are in flight
+            const uint64_t b = B0 + (uint64_t)q * kBlock + t;
+            code[q] = b < n_bases ? bases[b] : (uint32_t)'N';
+        }
+        if (wave == 0) {
+            // read holding the first base of the tile: largest r with read_offsets[r] <= B0.  Carried over from the previous tile,
+            // else a 64-ary search (every lane probes one offset per round)
+            uint64_t r0 = next_read0;
+            if (r0 == ~0ull) {
+                uint64_t lo = 0, hi = n_reads; // invariant: read_offsets[lo] <= B0 < read_offsets[hi] (offsets[n_reads] = n_bases > B0)
+                while (hi - lo > 1) {
+                    const uint64_t step = (hi - lo + 63) >> 6, idx = lo + (uint64_t)lane * step;
+                    const bool le = idx < hi && read_offsets[idx] <= B0;
+                    const uint32_t c = (uint32_t)__popcll(__ballot(le)); // probes are ascending: the first c of them are <= B0 (c >= 1: lane 0 probes lo)
+                    lo = lo + (uint64_t)(c - 1) * step;
+                    hi = lo + step < hi ? lo + step : hi;
+                }
+                r0 = lo;
+            }
+            // offsets of the reads r0 .. r0 + 64 (beyond the last read: +infinity) and their first output slots
+            const uint64_t j0 = r0 + lane, j1 = r0 + kReadsStaged;
+            const uint64_t o0 = j0 <= n_reads ? read_offsets[j0] : ~0ull, o1 = j1 <= n_reads ? read_offsets[j1] : ~0ull;
+            const uint64_t k0 = j0 < n_reads ? kmer_offsets[j0] : 0ull;
+            R.roff[lane] = o0;
+            R.koff[lane] = k0;
+            if (lane == 0) { R.roff[kReadsStaged] = o1; R.koff[kReadsStaged] = 0; R.read0 = r0; }
+            if (lane < kTileQ / 64) R.start_plane[lane] = 0;
+            const uint64_t o_next = (uint64_t)__shfl((unsigned long long)o0, (int)((lane + 1) & 63)); // offset of read r0 + lane + 1
+            const uint64_t nxt = lane == 63 ? o1 : o_next;
+            // slow walk when a 65th read could start inside the tile (+ its k-1 tail) or a staged read that matters is empty
+            const bool empty_read = o0 != ~0ull && nxt == o0 && o0 < B0 + kTileQ + k;
+            const bool too_many = o1 != ~0ull && o1 < B0 + kTileQ + k;
+            const bool slow = __ballot(empty_read) != 0 || too_many;
+            if (lane == 0) R.slow = slow ? 1u : 0u;
+            const bool starts_here = lane >= 1 && o0 > B0 && o0 < B0 + kTileQ; // read r0 + lane starts at tile position o0 - B0 (> 0)
+            if (starts_here) atomicOr((unsigned long long *)&R.start_plane[(o0 - B0) >> 6], 1ull << ((o0 - B0) & 63));
+            // next tile: reads that start at or before its first base
+            const uint32_t adv = (uint32_t)__popcll(__ballot(lane >= 1 && o0 <= B0 + kTileQ));
+            next_read0 = slow || adv == 63 ? ~0ull : r0 + adv;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < kTileQ / 64) { // exclusive prefix counts of the start plane
+                const uint32_t c = (uint32_t)__popcll(R.start_plane[lane]);
+                R.start_cum[lane] = wave_scan<false>(c) - c;
+            } else {
+                (void)wave_scan<false>(0u);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
-            uint64_t b = B0 + (uint64_t)q * kBlock + t;
-            uint32_t c = b < n_bases ? base_code_dev(bases[b]) : 4u;
+            const uint32_t c = base_code_dev((uint8_t)code[q]);
             unsigned long long blo = __ballot(c & 1u), bhi = __ballot((c >> 1) & 1u), binv = __ballot(c >> 2);
             if (lane == 0) { uint32_t wi = q * (kBlock / 64) + wave; R.plane_lo[wi] = blo; R.plane_hi[wi] = bhi; R.plane_inv[wi] = binv; }
         }
-        if (wave == 0) {
+        if (wave == 1) {
             uint64_t bt = B0 + kTileQ + lane;
             uint32_t ct = (lane < k - 1 && bt < n_bases) ? base_code_dev(bases[bt]) : 4u;
             unsigned long long tlo = __ballot(ct & 1u), thi = __ballot((ct >> 1) & 1u), tinv = __ballot(ct >> 2);
@@ -961,9 +1118,16 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
             }
         }
         __syncthreads();
+        // the tile 2-bit packed: word j = bases [32 j, 32 j + 32) from the low / high code bit planes
+        if (t < kTileQ / 32 + 4) {
+            const uint32_t half = 32 * (t & 1);
+            const uint64_t pl = t / 2 < kPlaneWords ? R.plane_lo[t / 2] : 0, ph = t / 2 < kPlaneWords ? R.plane_hi[t / 2] : 0;
+            R.packed[t] = spread_bits((uint32_t)(pl >> half)) | (spread_bits((uint32_t)(ph >> half)) << 1);
+        }
+        __syncthreads();
         // w-mer hashes of the tile, both strands
         for (uint32_t j = t; j < kTileQ + n_win - 1; j += kBlock) {
-            uint64_t m = spread_bits(plane_window(R.plane_lo, j, w)) | (spread_bits(plane_window(R.plane_hi, j, w)) << 1);
+            const uint64_t m = tile_mer(R, j, w);
             R.hf[j] = (H)hash_mmer(m, ix.seed, w);
             R.hr[j] = (H)hash_mmer(kmer_rc(m, w), ix.seed, w);
         }
@@ -971,6 +1135,7 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
         // S0: one item per base position
         uint64_t out_idx[kQpt];
         uint32_t state[kQpt]; // 0 = no window here, 1 = window with a non-ACGT byte, 2 = valid k-mer (answer pending)
+        const bool slow = R.slow != 0;
         uint64_t r = R.read0;
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
@@ -982,16 +1147,23 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
             uint64_t fw = 0, rc = 0;
             Minimizer mn{0, 0};
             if (b < n_bases) {
-                while (r + 1 < n_reads && read_offsets[r + 1] <= b) ++r;
-                uint64_t rs = read_offsets[r], re = read_offsets[r + 1];
+                uint64_t rs, re, ko;
+                if (!slow) { // the read of position i: staged reads that start at or before it (from the start plane)
+                    const uint32_t wi = i >> 6;
+                    const uint32_t rl = R.start_cum[wi] + (uint32_t)__popcll(R.start_plane[wi] & (~0ull >> (63 - (i & 63))));
+                    rs = R.roff[rl]; re = R.roff[rl + 1]; ko = R.koff[rl];
+                } else {
+                    while (r + 1 < n_reads && read_offsets[r + 1] <= b) ++r;
+                    rs = read_offsets[r]; re = read_offsets[r + 1]; ko = kmer_offsets[r];
+                }
                 if (b >= rs && b + k <= re) {
-                    out_idx[q] = kmer_offsets[r] + (b - rs);
+                    out_idx[q] = ko + (b - rs);
                     state[q] = plane_window(R.plane_inv, i, k) == 0 ? 2u : 1u;
                 }
             }
             bool query = state[q] == 2;
             if (query) {
-                fw = spread_bits(plane_window(R.plane_lo, i, k)) | (spread_bits(plane_window(R.plane_hi, i, k)) << 1);
+                fw = tile_mer(R, i, k);
                 rc = kmer_rc(fw, k);
                 if (query) mn = window_minimizer(R, i, fw, rc, k, w);
             }
@@ -1003,7 +1175,7 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
             }
             tally.add(false, false, state[q] == 1);
         }
-        tile_resolve<SC>(S, ix);
+        tile_resolve<SC, true>(S, ix);
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             const bool pend = state[q] == 2;
