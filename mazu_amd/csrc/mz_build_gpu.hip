@@ -470,10 +470,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
     uint64_t n_mm = 0;
     BG_HIP(hipMemcpy(&n_mm, d_nsel, 8, hipMemcpyDeviceToHost));
     h.n_minimizers = n_mm;
-    {   // same rule as the host builder: records must stay small next to the key set
-        uint64_t rec_bytes = (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords * 8;
-        if (rec_bytes > std::max<uint64_t>(64ull << 20, 16 * n_mm)) { set_error("GPU build unsupported: host rule selects the BBHash minimizer MPHF"); return MZ_EINVAL; }
-    }
+    if (!use_direct_records(w, n_mm)) { set_error("GPU build unsupported: host rule selects the BBHash minimizer MPHF"); return MZ_EINVAL; }
     // bucket starts: psum[i] = occurrences before minimizer i (n_mm + 1 values); run_start == psum in monotone mode
     uint64_t *d_psum = nullptr;
     BG_HIP(buf.alloc(&d_psum, n_mm + 1));

@@ -659,6 +659,13 @@ static void scan_unitig(const uint64_t *useq, uint64_t s, uint64_t e, uint32_t k
     }
 }
 
+bool use_direct_records(uint32_t w, uint64_t n_mm) {
+    if (2 * w > 32) return false;
+    uint64_t per_key = 48;
+    if (const char *e = getenv("MZ_DIRECT_BYTES_PER_KEY")) per_key = strtoull(e, nullptr, 10);
+    const uint64_t rec_bytes = (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords * 8;
+    return rec_bytes <= std::max<uint64_t>(64ull << 20, per_key * n_mm);
+}
 uint32_t skew_fp_bits_for_build() {
     if (const char *e = std::getenv("MZ_TEST_SKEW_FP_BITS")) {
         const int v = std::atoi(e);
@@ -815,12 +822,8 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     phase("sort + dedup + run-length");
     // 3. MPHF over the minimizer set, gamma = 1.7 (sshash.rs:177)
     // 2w <= 32: direct-address monotone MPHF (one line per probe, exact membership); else BBHash levels
-    //   (only while the records stay small next to the key set: at most max(64 MiB, 16 B per key))
-    bool use_direct = 2 * w <= 32;
-    if (use_direct) {
-        uint64_t rec_bytes = (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords * 8;
-        use_direct = rec_bytes <= std::max<uint64_t>(64ull << 20, 16 * n_mm);
-    }
+    //   (only while the records stay small next to the key set: use_direct_records())
+    const bool use_direct = use_direct_records(w, n_mm);
     int rc = use_direct ? mm.build_direct(mm_set.data(), n_mm, 2 * w, nt) : mm.build(mm_set.data(), n_mm, 1.7, nt);
     if (rc != MZ_OK) return rc;
     phase("minimizer mphf");
