@@ -25,7 +25,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 B_ALG = 208.0        # algorithmic bytes per k-mer query on the 50/50 mix, reference layout (table in DESIGN.md)
-B_ALG_OWN = 134.0    # same accounting for this repository's layout
+B_ALG_OWN = {True: 191.0, False: 134.0}  # same accounting for this repository's layout: with minimizer lines / minimizer records only
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, 8.0 TB/s spec
 
 DEFAULT_BATCH = {"s-tiny": 200_000, "s-yeast": 10_000_000, "s-txome": 50_000_000, "s-eighth": 50_000_000, "s-human": 125_000_000,
@@ -167,14 +167,15 @@ def bench_projection(ix, us, d_recs, n, dev, torch, np, steps=5):
     from mazu_amd._capi import check, lib
     n_u = us["n_unitigs"]
     starts = us["starts"]
-    # one forward/backward occurrence per unitig on a single reference laid out like the unitig concatenation
-    pos = starts[:-1].clone()
+    # one forward/backward occurrence per unitig on references of 2^30 bases cut from the unitig concatenation
+    ref_log = min(30, int(us["total_len"]).bit_length())
+    pos, ref = starts[:-1] & ((1 << ref_log) - 1), starts[:-1] >> ref_log
     g = torch.Generator(device=dev)
     g.manual_seed(5)
     fwd = torch.randint(0, 2, (n_u,), generator=g, device=dev, dtype=torch.int64)
-    pos_bits, ref_bits = int(us["total_len"]).bit_length(), 1
+    pos_bits, ref_bits = ref_log, max(1, int(us["total_len"] >> ref_log).bit_length())
     width, ref_shift = 1 + pos_bits + ref_bits, pos_bits + 1
-    enc = (pos << 1) | fwd                                               # ref_id 0: UnitigOcc::encode_piscem, src/spt_compact.rs:90-96
+    enc = (ref << ref_shift) | (pos << 1) | fwd                          # UnitigOcc::encode_piscem, src/spt_compact.rs:90-96
     bit = torch.arange(n_u, device=dev, dtype=torch.int64) * width
     wi, sh = bit >> 6, bit & 63
     words = torch.zeros((n_u * width + 63) // 64 + 2, dtype=torch.int64, device=dev)
@@ -384,7 +385,7 @@ def main():
             "hit_fraction": round(n_hit / total_q, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "frac_own_layout": round(batch * B_ALG_OWN / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_own_layout": round(batch * B_ALG_OWN[bool(ix.has_minimizer_lines())] / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic_gbs": round(traffic / avg_kernel_s / 1e9, 1) if traffic else None,
                          "kernel": {"v1": "k2u_batch_kernel", "tile": "k2u_tile_kernel"}.get(os.environ.get("MZ_K2U_KERNEL", ""), "k2u_wave_kernel"), "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_kmer": B_ALG},
