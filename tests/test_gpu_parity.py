@@ -358,6 +358,39 @@ def test_reads_edge_shapes(yeast):
     assert counts[2] == 40 - k + 1
 
 
+@pytest.mark.parametrize("w,skew", [(15, 32), (12, 16)])  # BBHash levels / direct-address minimizer records
+def test_reads_crowded_and_very_long(yeast, w, skew):
+    """tiles of the reads kernel touched by more reads than it stages (runs of 16-base, 1-base and empty reads: 64 and more read
+    starts per 1024 positions), reads longer than several tiles, and reads whose ends fall on tile boundaries, in one batch:
+    every window equals the oracle's, and read bookkeeping carried from tile to tile stays right after each kind of tile"""
+    k, seqs = yeast
+    ix, orc, _ = both(seqs, k, w, skew)
+    ref = H.read_fasta(CF_YEAST + ".fa")[0][1]
+    rng = np.random.default_rng(11)
+    reads, at = [], 1000
+
+    def take(n):
+        nonlocal at
+        at += int(rng.integers(0, 50))
+        r = ref[at:at + n]
+        at += n
+        return r
+    for block in range(6):
+        reads += [take(16) for _ in range(200)]                       # exactly 64 reads per 1024 bases
+        reads.append(take(3000))                                      # spans three tiles and more
+        reads += [take(int(rng.integers(0, 4))) for _ in range(300)]  # empty and 1..3-base reads: hundreds per tile
+        reads.append(take(k + int(rng.integers(0, 10))))
+        reads += [take(int(rng.choice([0, 5, 31, 33, 40, 64, 200]))) for _ in range(150)]
+        pad = (-sum(len(r) for r in reads)) % 1024                    # the next read starts exactly on a tile boundary
+        reads.append(take(pad if pad >= k else pad + 1024))
+        reads.append(take(1024))                                      # exactly one tile
+    bases, ro = reads_fixture([("", r) for r in reads])
+    got, counts = ix.k2u_reads(bases, ro, streaming=True)
+    want, ko, oc = orc.k2u_reads(bases, ro, streaming=True)
+    assert got.tobytes() == want.tobytes() and list(counts) == oc.tolist()
+    assert counts[0] > 0.9 * int(ko[-1])                              # slices of the reference: nearly every window is a hit
+
+
 @pytest.mark.parametrize("prefix,w,skew", [(CF_TINY, 3, M.MZ_NO_SKEW_INDEX), (CF_TINY, 5, 0), (CF_TINY, 1, 2), (CF_TINY, 7, M.MZ_NO_SKEW_INDEX),
                                            (CF_YEAST, 12, 16), (CF_YEAST, 13, 32), (CF_YEAST, 9, 4), (CF_YEAST, 4, M.MZ_NO_SKEW_INDEX),
                                            (CF_YEAST, 15, 16), (CF_YEAST, 20, 8)])
