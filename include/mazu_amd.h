@@ -4,7 +4,7 @@
  * This is the drop-in boundary for ONE path of COMBINE-lab/mazu: the `K2U`
  * implementation `SSHash` (reference src/kphf/sshash.rs) behind the trait
  * surface of src/kphf/mod.rs:58-140.  A Rust `impl K2U for GpuSSHash` binds
- * exactly these symbols (INTEGRATION.md shows the stub).  Plain pointers and
+ * exactly these symbols.  Plain pointers and
  * sizes only; no C++ or torch types.
  *
  * Conventions shared with the reference

@@ -1,4 +1,4 @@
-// mz_build_gpu.hip -- index construction on the device (SURVEY.md 8(f) rank 2).
+// mz_build_gpu.hip -- index construction on the device.
 //
 // Produces, array for array and bit for bit, what SSHashHost::build (mz_host.cpp, the restatement of
 // reference src/kphf/sshash.rs:86-329 in this repository's layout) produces on the host:

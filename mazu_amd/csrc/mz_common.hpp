@@ -48,7 +48,7 @@ constexpr uint64_t kP3 = 0x589965cc75374cc3ull;
 
 // Minimizer order: WyHashState(seed) applied to the w-mer word (kphf/mod.rs:32-52).  A
 // wyhash-style two-round mum of the 8-byte key; bit-compat with the wyhash crate is not
-// needed for result parity (note A) and is unpinned.
+// needed for result parity (a unique k-mer has one position whatever the minimizer order) and is unpinned.
 // For w <= 16 the word fits 32 bits and the 32-bit member of the wyhash family (two 32x32->64
 // multiply-folds, cf. wyhash32) is used: 4 quarter-rate multiplies on CDNA4 instead of ~20.
 MZ_HD uint64_t hash_mmer64(uint64_t x, uint64_t seed) { return mum(mum(x ^ kP0, seed ^ kP1) ^ kP2, kP3); }
@@ -803,7 +803,8 @@ MZ_HD mz_k2upos lookup_with_minimizer(const IndexView &ix, uint64_t fw, uint64_t
         // Entry = (minimizer position << 1) | class.  Class 0: the occurrence was emitted by a
         // forward-canonical k-mer, so only candidate A (:498) can be a true occurrence; class 1:
         // reverse-canonical, only candidate B (:527).  The other candidate of the reference loop
-        // can never verify ("strand class bit"), so skipping it keeps results identical.
+        // can never verify: had B verified on a class-0 entry, the verified k-mer would be reverse-canonical and would itself have
+        // emitted this (word, position) with class 1, which is its own entry.  Skipping the other candidate keeps results identical.
         uint64_t ent = ix.pos[pi];
         const bool cls = (ent >> kEntryFlankBits) & 1;
         uint64_t mm_pos = ent >> kEntryShift, off = cls ? off_b : off_a;

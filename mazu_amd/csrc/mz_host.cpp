@@ -1,6 +1,6 @@
 // mz_host.cpp -- index construction on the host (multi-threaded C++17).
 // Steps mirror reference src/kphf/sshash.rs:86-329; the produced arrays are the HBM layout
-// described in DESIGN.md.  No query code lives here: queries run on the GPU only.
+// described next to the views in mz_common.hpp.  No query code lives here: queries run on the GPU only.
 #include "mz_host.hpp"
 
 #include <algorithm>

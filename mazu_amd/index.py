@@ -244,7 +244,7 @@ class ModIndex:  # src/index.rs:49-124
     def as_streaming(self):  # src/index/caching.rs:221-232
         return StreamingIndex(self)
 
-    # ---- device-resident forms (k2u AND the projection on the GPU)
+    # ---- device-resident forms: k2u AND the projection on the GPU
     def get_ref_pos_batch(self, fw_words, cap=None):
         """get_ref_pos_eager for a batch: returns (offsets[n+1], MappedRefPos records grouped by query)"""
         fw = np.ascontiguousarray(fw_words, dtype=np.uint64)

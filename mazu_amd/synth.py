@@ -1,4 +1,4 @@
-"""Synthetic unitig sets and query mixes for bench.py and the large-size tests (SURVEY.md 8(d)).
+"""Synthetic unitig sets and query mixes for bench.py and the large-size tests.
 
 Everything is generated with torch ops on whatever device the generator lives on (the GPU in
 bench.py, the CPU in the `not gpu` tests), from a counter-free seeded torch.Generator, so every

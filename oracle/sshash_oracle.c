@@ -19,7 +19,8 @@
  *     reference test asserts any of those values.  The published algorithms
  *     are restated here (BBHash levels, Vigna's Elias-Fano, a wyhash-style
  *     mum hash); for unitig sets with unique canonical k-mers the results do
- *     not depend on them (note A).
+ *     not depend on them: a unique k-mer has one position, whatever the
+ *     minimizer order and MPHF slots used to find it.
  *
  * Also contains a brute-force dictionary (sorted canonical k-mer -> global
  * position) that is independent of every succinct structure below; it is the
@@ -48,7 +49,7 @@ typedef struct {
 #define ORC_SKIPPED 3u
 
 /* ------------------------------------------------------------------ */
-/* Word-touch counter (SURVEY.md 8(d)): when enabled, every 8-byte word a QUERY reads from the index arrays of
+/* Word-touch counter: when enabled, every 8-byte word a QUERY reads from the index arrays of
  * this restatement (reference layout: BBHash levels + rank samples, Elias-Fano high/low/select samples, packed pos,
  * 2-bit sequence, boundary bit vector + rank samples) is tallied; orc_word_touches() reports the total.  It counts
  * words per access site (a word read twice by two sites counts twice; the sites of one query rarely overlap). */
@@ -197,7 +198,7 @@ static void ef_free(efvec *e) { bv_free(&e->high); iv_free(&e->low); }
 
 /* ------------------------------------------------------------------ */
 /* 2-bit sequence: base i at bits [2i,2i+1] of word i/32, first base in LSBs,
- * A=0 C=1 G=2 T=3 (pinned by the pufferfish fixtures)      */
+ * A=0 C=1 G=2 T=3 (pinned by the pufferfish fixtures under tests/golden)  */
 static inline int base_code(uint8_t c) {
     switch (c) {
     case 'A': case 'a': return 0;
@@ -914,4 +915,4 @@ int orc_ef_roundtrip(const uint64_t *xs, uint64_t n, uint64_t u, uint64_t *out) 
     if (rc != -2) ef_free(&e);
     return rc;
 }
-/* average number of 8-byte words a query touches is not modelled here; see DESIGN.md */
+/* (the average number of 8-byte words a query touches is measured by the word-touch counter above, not modelled here) */

@@ -1,5 +1,5 @@
 """Shared test helpers: 2-bit packing (A=0 C=1 G=2 T=3, first base in the LSBs,
-SURVEY 8(a) a7), fixture readers, seeded synthetic unitig sets and query mixes."""
+as in the reference's UnitigSet), fixture readers, seeded synthetic unitig sets and query mixes."""
 import json
 import os
 
@@ -127,7 +127,7 @@ def valid_kmer_positions(starts, k):
 
 def query_mix(words, starts, k, n, seed, neg_frac=0.5):
     """n forward words: positives drawn from valid positions (random orientation),
-    negatives uniform random 2k-bit words (NEG-U, SURVEY 8(d)); shuffled."""
+    negatives uniform random 2k-bit words (NEG-U); shuffled."""
     rng = np.random.default_rng(seed)
     vp = valid_kmer_positions(starts, k)
     n_neg = int(n * neg_frac)

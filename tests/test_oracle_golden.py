@@ -1,5 +1,5 @@
 """Pins the CPU oracle (oracle/sshash_oracle.c) against every known-answer test the
-reference holds for the k2u path (SURVEY.md 8(c)).  CPU only."""
+reference holds for the k2u path.  CPU only."""
 import json
 import os
 
