@@ -1,5 +1,5 @@
 // mz_host.hpp -- host-side owner of the index layout (the role of the Rust host code in the reference):
-// "Rust host code"): UnitigSet, Elias-Fano, rank-interleaved MPHF and the SSHash builder.
+// UnitigSet, Elias-Fano, rank-interleaved MPHF and the SSHash builder.
 // Follows the construction steps of reference src/kphf/sshash.rs:86-329 but lays every
 // structure out for 128-byte-line gathers on MI355X (one dependent step = one line; layouts in mz_common.hpp).
 #pragma once
