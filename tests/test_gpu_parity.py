@@ -288,8 +288,8 @@ def test_save_load_roundtrip_on_gpu(yeast, tmp_path):
 
 
 def test_synthetic_s_yeast_scale_properties():
-    """BASELINE config[1] scale (12 Mbp, planted minimizer skew): validate_self on the device,
-    50/50 mix hit rate, rc symmetry, and a 200k sample against the oracle."""
+    """BASELINE config[1] at its size (12 Mbp, planted minimizer skew, ONE batch of 10 M queries): validate_self on the device,
+    50/50 mix hit rate, and a 200k sample of the batch against the oracle."""
     import torch
     from mazu_amd import synth
     us = synth.make_unitig_set("s-yeast", device="cuda")
@@ -300,13 +300,13 @@ def test_synthetic_s_yeast_scale_properties():
     assert ix.n_kmers_in_skew_index() > 0
     rep = ix.validate_self_report()
     assert rep["n_fail"] == 0 and rep["n_kmers"] == ix.n_kmers() and rep["n_duplicate"] <= 4
-    q = synth.make_query_mix(ix, us, 2_000_000, seed=3, device="cuda")
+    q = synth.make_query_mix(ix, us, 10_000_000, seed=3, device="cuda")
     out = torch.zeros(q.numel() * 2, dtype=torch.int64, device="cuda")
     cnt = torch.zeros(3, dtype=torch.int64, device="cuda")
     ix.k2u_batch_device(q, out, cnt, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     n_hit, n_miss, _ = cnt.cpu().tolist()
-    assert n_hit + n_miss == q.numel() and abs(n_hit - q.numel() // 2) <= 8
+    assert n_hit + n_miss == q.numel() and abs(n_hit - q.numel() // 2) <= 40  # NEG-U words that happen to be members
     orc = O.OracleSSHash(words, us["total_len"], starts, 31, 15, 32, with_dict=False)
     qs = q[:200000].cpu().numpy().view(np.uint64)
     want, _ = orc.k2u_batch(qs, n_threads=8)
