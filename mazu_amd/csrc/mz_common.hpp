@@ -515,16 +515,20 @@ MZ_HD uint32_t front_line_members(const uint64_t *minrec, uint32_t g, uint64_t l
     bucket0 = (hdr & kMinRecRankMask) + (hdr >> 40) + popc64(wv & ~(~0ull << bi));
     return (uint32_t)((wv >> bi) & ((1ull << (1u << g)) - 1)); // 2^g <= 16 keys never straddle a bitmap word
 }
-// g for a key universe of 2^(2w) and n_occ entries, or -1 when minimizer lines do not pay: the largest g <= 4 that keeps
-// the mean line load at or under 10 of 16 slots, provided the table stays within max(64 MiB, 40 bytes per entry)
+// g for a key universe of 2^(2w) and n_occ entries, or -1 when minimizer lines do not pay.  The table must stay within
+// max(64 MiB, 40 bytes per entry).  Preferred: the largest g <= 4 with a mean line load of at most 5 of the 16 slots (about
+// 94 % of the entry mass then sits inline and 3 % spills); if that table is too large, the largest g with a load of at most 10
+// (88 % inline, 9 % spilled).
 MZ_HD int front_choose_g(uint32_t w, uint64_t n_occ) {
     if (2 * w > 32) return -1;
-    for (int g = (int)(2 * w < kFrontMaxG ? 2 * w : kFrontMaxG); g >= 0; --g) {
-        const uint64_t n_lines = 1ull << (2 * w - g);
-        if (n_occ > 10 * n_lines) continue;
-        const uint64_t bytes = n_lines * kFrontSlots * 8, cap = 40 * n_occ > (64ull << 20) ? 40 * n_occ : (64ull << 20);
-        return bytes <= cap ? g : -1;
-    }
+    const uint64_t cap = 40 * n_occ > (64ull << 20) ? 40 * n_occ : (64ull << 20);
+    for (uint64_t max_load = 5; max_load <= 10; max_load += 5)
+        for (int g = (int)(2 * w < kFrontMaxG ? 2 * w : kFrontMaxG); g >= 0; --g) {
+            const uint64_t n_lines = 1ull << (2 * w - g);
+            if (n_occ > max_load * n_lines) continue;
+            if (n_lines * kFrontSlots * 8 <= cap) return g;
+            break; // smaller g only makes the table larger
+        }
     return -1;
 }
 

@@ -348,7 +348,10 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     //          S5, a skew-index request for S4, or -- for a bucket that did not fit its line -- its range in the entry array
     //          for S3.  A query none of whose line's slots carries its key is a miss.
     if (ix.front.lines != nullptr) {
-        constexpr int kFR = 8;                                 // rounds (of 8 queries) whose lines are in flight together
+#ifndef MZ_SF_BATCH
+#define MZ_SF_BATCH 8
+#endif
+        constexpr int kFR = MZ_SF_BATCH;                       // rounds (of 8 queries) whose lines are in flight together
         constexpr uint32_t kRounds = 64 * kQpt / 8;            // per wavefront: 8 queries per 64 lanes and round
         const uint32_t lane = t & 63, sub = lane & 7, grp = lane >> 3, g = ix.front.g;
         const uint32_t wave_q0 = (t >> 6) * (64 * kQpt);      // first item of this wave's share of the tile

@@ -723,7 +723,7 @@ int FrontTable::choose_g(uint32_t w, uint64_t n_occ, bool direct) {
             if (n_occ <= 10 * (1ull << (2 * w - g))) return g;
         return -1;
     }
-    if (const char *l = std::getenv("MZ_FRONT_MAX_LOAD")) { // experiments: mean slots per line allowed (default 10, see front_choose_g)
+    if (const char *l = std::getenv("MZ_FRONT_MAX_LOAD")) { // experiments: mean slots per line allowed (front_choose_g prefers 5 and accepts 10)
         const double load = std::atof(l);
         if (load > 0 && 2 * w <= 32)
             for (int g = (int)std::min<uint32_t>(2 * w, kFrontMaxG); g >= 0; --g)

@@ -3,7 +3,7 @@
     python tools/front_stats.py s-human
 
 Builds the index on the GPU, reads its entry array back from the flat file, derives (key, bucket size) and simulates, for
-several keys-per-line settings, how much of the entry mass a line of 16 slots holds inline."""
+several (slots per line, keys per line) settings, how much of the entry mass a line holds inline."""
 import struct
 import sys
 import time
@@ -76,7 +76,7 @@ print("bucket count by size (last = 40+):", h.tolist())
 print("entry mass by size:", (h * np.arange(len(h)) / n_ent).round(4).tolist())
 heavy = sizes > skew
 print("heavy buckets:", int(heavy.sum()), "entry mass in heavy:", round(sizes[heavy].sum() / n_ent, 4))
-for g in (2, 3, 4, 5, 6, 7):
+for slots, g in ((16, 3), (16, 4), (8, 1), (8, 2), (8, 3), (8, 4)):
     line = keys >> g
     # greedy by ascending size inside a line, one slot reserved for the marker of every bucket not (yet) inline
     s_eff = np.where(heavy, 1 << 20, sizes)
@@ -89,12 +89,12 @@ for g in (2, 3, 4, 5, 6, 7):
     rank = np.arange(len(l_s)) - idx_first[grp]
     cs = np.cumsum(z_s)
     cs_excl_line = cs - (cs[idx_first[grp]] - z_s[idx_first[grp]])  # inclusive cumsum inside the line
-    inline = cs_excl_line + (m[grp] - rank - 1) <= 16
+    inline = cs_excl_line + (m[grp] - rank - 1) <= slots
     light = z_s < (1 << 20)
     mass_inline = z_s[inline & light].sum() / n_ent
     n_lines = (1 << 30) >> g
     used = np.zeros(len(m), dtype=np.int64)
     np.add.at(used, grp, np.where(inline, z_s, 1))
-    print(f"g={g}: {n_lines} lines = {n_lines * 128 / 1e9:.2f} GB, occupied lines {len(m)}, mean slots used in occupied lines {used.mean():.2f}, "
+    print(f"slots={slots} g={g}: {n_lines} lines = {n_lines * slots * 8 / 1e9:.2f} GB, occupied lines {len(m)}, mean slots used in occupied lines {used.mean():.2f}, "
           f"entry mass inline {mass_inline:.4f}, buckets inline {inline.mean():.4f}, "
           f"entry mass spilled {z_s[~inline & light].sum() / n_ent:.4f}", flush=True)
