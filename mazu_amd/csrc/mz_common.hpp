@@ -388,8 +388,8 @@ struct IndexView {
     uint64_t total_len;
     uint64_t n_unitigs;
     uint64_t skew_param;
-    const uint64_t *seqbv;     // 128-byte records: words 0..7 = 256 bases of the 2-bit packed unitig concatenation,
-                               // words 8..15 = the boundary block of the same 256 bases (verify + locate share ONE line)
+    const uint64_t *seqbv;     // 64-byte records: words 0..3 = 128 bases of the 2-bit packed unitig concatenation,
+                               // words 4..7 = the unitig boundaries of the same 128 bases (verify + locate share ONE access)
     MphfView mm;               // minimizer -> bucket id
     BefView buckets;           // bucket id -> [start,end) in pos  (occs_prefix_sum, partitioned Elias-Fano)
     const uint64_t *pos;       // packed entries: (minimizer position << 17) | (strand class << 16) | flank16
@@ -677,11 +677,17 @@ MZ_HD UnitigSpan locate_unitig(const uint64_t *b, uint32_t off, uint64_t base) {
 
 
 // ---- interleaved sequence / boundary records (IndexView::seqbv) ----------------------------------------
-constexpr uint32_t kSeqRecWords = 16;
-// Record r holds the 256 bases [224 r, 224 r + 256) and their boundary block: consecutive records overlap by 32 bases,
-// so a k-mer (k <= 31) starting at any position lies inside ONE record (r = pos / 224) and its verification never costs
-// a second line.  224 bases = 7 words, so the base words of record r are words 7r .. 7r+7 of the packed sequence.
-constexpr uint32_t kSeqRecStride = 224, kSeqRecStrideWords = kSeqRecStride / 32;
+// One 64-byte record per 96 bases, holding 128: record r = bases [96 r, 96 r + 128) (words 0..3, the 2-bit packed bases:
+// 96 bases = 3 words, so these are words 3r .. 3r+3 of the packed sequence) + the unitig boundaries of the same 128 bases:
+//   w4 = id of the unitig holding the record's first base | low 32 bits of that unitig's start << 32
+//   w5 = end (exclusive) of the unitig holding the record's last base (36 bits) | bits 32..35 of the start << 36
+//   w6, w7 = one bit per base, set at the LAST base of every unitig (unitig_set.rs:90-96)
+// Consecutive records overlap by 32 bases, so a k-mer (k <= 31) starting at any position lies inside ONE record
+// (r = pos / 96) and its verification plus the unitig lookup (== bv.rank(pos) + accum_lens.get(id) + accum_lens.get(id+1),
+// unitig_set.rs:178-204) cost one random 64-byte access -- half a 128-byte line, which the memory system serves at a
+// higher rate than accesses that touch both halves.
+constexpr uint32_t kSeqRecWords = 8;
+constexpr uint32_t kSeqRecStride = 96, kSeqRecStrideWords = kSeqRecStride / 32, kSeqRecBases = 128;
 MZ_HD uint64_t seq_rec_of(uint64_t pos, uint32_t &off) { // positions are < 2^36 (kPosBits)
     const uint32_t r = (uint32_t)(pos >> 5) / kSeqRecStrideWords;
     off = (uint32_t)(pos - (uint64_t)r * kSeqRecStride);
@@ -690,15 +696,33 @@ MZ_HD uint64_t seq_rec_of(uint64_t pos, uint32_t &off) { // positions are < 2^36
 MZ_HD uint64_t read_kmer_i(const uint64_t *rec, uint64_t pos, uint32_t k) {
     uint32_t off;
     const uint64_t *R = rec + seq_rec_of(pos, off) * kSeqRecWords;
-    const uint32_t wi = off >> 5, sh = 2 * (off & 31); // off <= 223: wi + 1 <= 7
+    const uint32_t wi = off >> 5, sh = 2 * (off & 31); // off <= 95: wi + 1 <= 3
     const uint64_t lo = R[wi], hi = R[wi + 1];
     const uint64_t x = (lo >> sh) | ((hi << 1) << (63 - sh)); // branch-free funnel shift (sh == 0: second term vanishes): both loads stay unconditional
     return x & kmer_mask(k);
 }
+MZ_HD void seq_rec_header(uint64_t id0, uint64_t start0, uint64_t end_last, uint64_t &h0, uint64_t &h1) {
+    h0 = id0 | (start0 << 32);
+    h1 = end_last | ((start0 >> 32) << 36);
+}
+// boundary half of a record given by value: unitig id, start and end of the unitig that holds base `base + off` (off < 128)
+MZ_HD UnitigSpan locate_unitig_r(uint64_t h0, uint64_t h1, uint64_t d0, uint64_t d1, uint32_t off, uint64_t base) {
+    const bool up = off >= 64;
+    const uint64_t below = ~(~0ull << (off & 63));                    // bits under `off` inside its word
+    const uint64_t lo0 = up ? d0 : d0 & below, lo1 = up ? d1 & below : 0; // boundary bits strictly below off
+    const uint64_t hi0 = up ? 0 : d0 & ~below, hi1 = up ? d1 & ~below : d1; // ... at or above off
+    UnitigSpan s;
+    s.id = (h0 & 0xFFFFFFFFull) + popc64(lo0) + popc64(lo1);
+    const uint64_t start0 = (h0 >> 32) | ((h1 >> 36) << 32), end_last = h1 & ((1ull << 36) - 1);
+    s.start = lo1 ? base + 128 - clz64(lo1) : lo0 ? base + 64 - clz64(lo0) : start0;   // after the highest boundary below off
+    s.end = hi0 ? base + ctz64(hi0) + 1 : hi1 ? base + 65 + ctz64(hi1) : end_last;      // through the lowest boundary at or above off
+    return s;
+}
 MZ_HD UnitigSpan locate_unitig_i(const uint64_t *rec, uint64_t pos) {
     uint32_t off;
     const uint64_t r = seq_rec_of(pos, off);
-    return locate_unitig(rec + r * kSeqRecWords + 8, off, r * kSeqRecStride);
+    const uint64_t *R = rec + r * kSeqRecWords;
+    return locate_unitig_r(R[4], R[5], R[6], R[7], off, r * kSeqRecStride);
 }
 
 // ---- `pos` entry: (minimizer position << 17) | (strand class << 16) | flank16 ---------------------

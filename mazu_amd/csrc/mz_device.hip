@@ -124,19 +124,19 @@ __device__ __forceinline__ uint32_t query_flank(uint64_t g, uint32_t off, uint32
     return ql | (qr << 8);
 }
 
-// boundary half of a sequence+boundary record, fetched as four 16-byte loads (records are 128-byte aligned)
+// boundary half of a sequence+boundary record, fetched as two 16-byte loads (records are 64-byte aligned)
 struct SeqBoundary {
-    ulonglong2 h01, h23, d01, d23;
+    ulonglong2 h, d;
 };
 __device__ __forceinline__ SeqBoundary load_boundary(const uint64_t *seqbv, uint64_t pos) {
     uint32_t off;
-    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(seqbv + seq_rec_of(pos, off) * kSeqRecWords + 8);
-    return SeqBoundary{v[0], v[1], v[2], v[3]};
+    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(seqbv + seq_rec_of(pos, off) * kSeqRecWords + 4);
+    return SeqBoundary{v[0], v[1]};
 }
 __device__ __forceinline__ UnitigSpan locate_boundary(const SeqBoundary &b, uint64_t pos) {
     uint32_t off;
     const uint64_t r = seq_rec_of(pos, off);
-    return locate_unitig_w(b.h01.x, b.h01.y, b.h23.x, b.d01.x, b.d01.y, b.d23.x, b.d23.y, off, r * kSeqRecStride);
+    return locate_unitig_r(b.h.x, b.h.y, b.d.x, b.d.y, off, r * kSeqRecStride);
 }
 
 // Execution scope of a tile: a whole 256-thread workgroup (barriers) or ONE wavefront (no barriers: the four
@@ -749,7 +749,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
         SC::sync();
     }
     if constexpr (kStopAfter == 4) return;
-    // ---- S5: every item has at most one recorded candidate position.  ONE gather of its 128-byte sequence+boundary record
+    // ---- S5: every item has at most one recorded candidate position.  ONE gather of its 64-byte sequence+boundary record
     //          verifies the k-mer (sshash.rs:500-504) and yields unitig id / offset / length (:509-514); the answer is parked
     //          in the item's own slot[] / n[] words, which are dead by now.  Candidates are compacted first, so the gathers
     //          are issued by full waves, two records in flight per lane.

@@ -435,9 +435,9 @@ int UnitigSet::finish() {
     return MZ_OK;
 }
 
-// interleave the packed sequence and the boundary blocks into 128-byte records (IndexView::seqbv).  The boundary bits of a
-// record are cut out of the boundary bit vector (bv_blocks, the reference's `bv`: a bit at the last base of every unitig,
-// unitig_set.rs:90-96); the header words come from the offsets.
+// interleave the packed sequence and the unitig boundaries into 64-byte records (IndexView::seqbv, layout at seq_rec_of).
+// The boundary bits of a record are cut out of the boundary bit vector (bv_blocks, the reference's `bv`: a bit at the
+// last base of every unitig, unitig_set.rs:90-96); the header words come from the offsets.
 void UnitigSet::build_seqbv() {
     const uint64_t nr = (total_len + kSeqRecStride - 1) / kSeqRecStride + 1; // + a tail record: never probed by a valid position
     seqbv.assign(nr * kSeqRecWords, 0);
@@ -449,27 +449,25 @@ void UnitigSet::build_seqbv() {
     uint64_t uid = 0; // unitig holding the first base of the current record
     for (uint64_t r = 0; r < nr; ++r) {
         uint64_t *W = seqbv.data() + r * kSeqRecWords;
-        for (uint32_t j = 0; j < 8; ++j) {
+        for (uint32_t j = 0; j < kSeqRecBases / 32; ++j) {
             const uint64_t wi = r * kSeqRecStrideWords + j;
             W[j] = wi < nw ? useq[wi] : 0;
         }
         const uint64_t first = r * kSeqRecStride;
         if (first >= total_len) {
-            W[8] = n_unitigs; W[9] = total_len; W[10] = total_len;
+            seq_rec_header(n_unitigs, total_len, total_len, W[4], W[5]);
             continue;
         }
-        const uint64_t lastb = std::min<uint64_t>(first + kBvBasesPerBlock - 1, total_len - 1);
-        for (uint32_t j = 0; j < 4; ++j) { // bits [first + 64 j, first + 64 j + 64): first is a multiple of 32
+        const uint64_t lastb = std::min<uint64_t>(first + kSeqRecBases - 1, total_len - 1);
+        for (uint32_t j = 0; j < kSeqRecBases / 64; ++j) { // bits [first + 64 j, first + 64 j + 64): first is a multiple of 32
             const uint64_t b = first + 64ull * j, wi = b >> 6;
             const uint32_t sh = (uint32_t)(b & 63);
-            W[12 + j] = sh ? (bv_word(wi) >> sh) | (bv_word(wi + 1) << (64 - sh)) : bv_word(wi);
+            W[6 + j] = sh ? (bv_word(wi) >> sh) | (bv_word(wi + 1) << (64 - sh)) : bv_word(wi);
         }
         while (starts[uid + 1] <= first) ++uid;
         uint64_t ul = uid; // -> the unitig holding the last base of the record
         while (starts[ul + 1] <= lastb) ++ul;
-        W[8] = uid;
-        W[9] = starts[uid];
-        W[10] = starts[ul + 1];
+        seq_rec_header(uid, starts[uid], starts[ul + 1], W[4], W[5]);
     }
 }
 

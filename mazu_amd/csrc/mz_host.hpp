@@ -75,7 +75,7 @@ struct UnitigSet {
     std::vector<uint64_t> starts;    // n_unitigs + 1 (plain copy of accum_lens)
     EFVector accum_lens;             // as in the reference
     std::vector<uint64_t> bv_blocks; // boundary bit vector, rank/select-interleaved blocks
-    std::vector<uint64_t> seqbv;     // 128-byte records {256 bases | their boundary block}: what the query path reads
+    std::vector<uint64_t> seqbv;     // 64-byte records {128 bases | their unitig boundaries}: what the query path reads
     void build_seqbv();
 
     int from_packed(const uint64_t *words, uint64_t total_len_, const uint64_t *starts_, uint64_t n, uint32_t k_);
