@@ -50,14 +50,18 @@ constexpr uint64_t kP3 = 0x589965cc75374cc3ull;
 // wyhash-style two-round mum of the 8-byte key; bit-compat with the wyhash crate is not
 // needed for result parity (a unique k-mer has one position whatever the minimizer order) and is unpinned.
 // For w <= 16 the word fits 32 bits and the 32-bit member of the wyhash family (two 32x32->64
-// multiply-folds, cf. wyhash32) is used: 4 quarter-rate multiplies on CDNA4 instead of ~20.
+// multiply-folds, cf. wyhash32) is used, cut to its top kMmerHash32Bits bits: the order is "smallest hash, leftmost
+// w-mer on ties", so a window minimum can be taken over single 32-bit keys (hash << position bits | position) with one
+// v_min_u32 per element -- (hash, offset in the k-mer) for a point query, (hash, position in the tile) for the sliding
+// minimum over a staged read tile.
+constexpr uint32_t kMmerHash32Bits = 21;
 MZ_HD uint64_t hash_mmer64(uint64_t x, uint64_t seed) { return mum(mum(x ^ kP0, seed ^ kP1) ^ kP2, kP3); }
-MZ_HD uint64_t hash_mmer32(uint32_t x, uint64_t seed) {
+MZ_HD uint32_t hash_mmer32(uint32_t x, uint64_t seed) {
     const uint32_t c0 = 0x53c5ca59u, c1 = 0x74743c1bu;
     uint64_t c = (uint64_t)(x ^ c0 ^ (uint32_t)seed) * (uint64_t)((c1 ^ (uint32_t)(seed >> 32)) | 1u);
     uint32_t a = (uint32_t)c ^ c0, b = (uint32_t)(c >> 32) ^ c1;
     c = (uint64_t)a * b;
-    return (uint32_t)c ^ (uint32_t)(c >> 32);
+    return ((uint32_t)c ^ (uint32_t)(c >> 32)) >> (32 - kMmerHash32Bits);
 }
 MZ_HD uint64_t hash_mmer(uint64_t x, uint64_t seed, uint32_t w) { return w <= 16 ? hash_mmer32((uint32_t)x, seed) : hash_mmer64(x, seed); }
 
@@ -81,18 +85,19 @@ MZ_HD void mphf_level_slot(uint64_t key, uint64_t level_seed, uint32_t n_blocks,
 MZ_HD uint64_t kmer_mask(uint32_t k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1); }
 
 MZ_HD uint64_t kmer_rc(uint64_t x, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // reversing all 64 bits reverses the bases and swaps the two bits of every base: swap them back, complement, align
+    uint32_t lo = __brev((uint32_t)(x >> 32)), hi = __brev((uint32_t)x);
+    lo = ~(((lo >> 1) & 0x55555555u) | ((lo << 1) & 0xAAAAAAAAu));
+    hi = ~(((hi >> 1) & 0x55555555u) | ((hi << 1) & 0xAAAAAAAAu));
+    return (((uint64_t)hi << 32) | lo) >> (64 - 2 * k);
+#else
     x = ~x;
     x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
     x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    lo = __builtin_bswap32(lo);
-    hi = __builtin_bswap32(hi);
-    x = ((uint64_t)lo << 32) | hi;
-#else
     x = __builtin_bswap64(x);
-#endif
     return x >> (64 - 2 * k);
+#endif
 }
 
 // k-mer starting at base `pos` of a packed sequence (two-word read; the array is padded)
@@ -166,11 +171,20 @@ struct Minimizer {
 MZ_HD Minimizer canonical_minimizer(uint64_t fw, uint64_t rc, uint32_t k, uint32_t w, uint64_t seed) {
     uint64_t g = fw <= rc ? fw : rc;
     uint64_t wmask = kmer_mask(w);
+    if (w <= 16) { // 21-bit hashes: the minimum of (hash << 5 | offset) is the smallest hash at its leftmost offset (k - w <= 30)
+        uint32_t best = ~0u;
+        for (uint32_t o = 0; o + w <= k; ++o) {
+            const uint32_t key = (hash_mmer32((uint32_t)((g >> (2 * o)) & wmask), seed) << 5) | o;
+            best = key < best ? key : best;
+        }
+        const uint32_t o = best & 31u;
+        return Minimizer{(g >> (2 * o)) & wmask, o};
+    }
     Minimizer best{g & wmask, 0};
-    uint64_t best_h = hash_mmer(best.word, seed, w);
+    uint64_t best_h = hash_mmer64(best.word, seed);
     for (uint32_t o = 1; o + w <= k; ++o) {
         uint64_t m = (g >> (2 * o)) & wmask;
-        uint64_t h = hash_mmer(m, seed, w);
+        uint64_t h = hash_mmer64(m, seed);
         if (h < best_h) { best_h = h; best.word = m; best.offset = o; }
     }
     return best;

@@ -976,7 +976,7 @@ constexpr int kPlaneWords = kTileQ / 64 + 2; // plane words incl. the k-1 tail a
 
 constexpr int kReadsStaged = 64; // reads whose offsets are staged per tile (a tile that more reads touch takes the slow walk)
 template <typename H> // H = uint32_t when the w-mer hash has 32 significant bits (w <= 16), else uint64_t
-struct ReadsLds {
+struct alignas(16) ReadsLds {
     uint64_t plane_lo[kPlaneWords], plane_hi[kPlaneWords], plane_inv[kPlaneWords];
     uint64_t packed[kTileQ / 32 + 4];            // the tile's bases 2-bit packed (base i at bits [2i, 2i+1] of word i / 32), built from the planes
     H hf[kTileQ + 32], hr[kTileQ + 32];          // w-mer hashes of the tile, forward / reverse-complement strand
@@ -1020,6 +1020,32 @@ __device__ __forceinline__ Minimizer window_minimizer(const ReadsLds<H> &R, uint
         mn.word = (rc >> (2 * mn.offset)) & kmer_mask(w);
     }
     return mn;
+}
+
+// Sliding minimum for the compile-time (k, w) = (31, 15) configuration.  The staged values are single 32-bit keys,
+// hash << 11 | tile position on the forward strand and hash << 11 | (2047 - tile position) on the reverse strand, so that
+// an unsigned minimum is the smallest hash at its leftmost position in the orientation of the canonical k-mer
+// (canonical_minimizer()'s tie rule).  Thread t takes the four windows that start at positions 4t .. 4t+3: their 17-key
+// spans share keys 4t+3 .. 4t+16, whose minimum is computed once; 20 keys come in as five 16-byte LDS reads.
+constexpr uint32_t kTilePosBits = 11;
+static_assert(kTileQ + 32 <= (1u << kTilePosBits) && kMmerHash32Bits + kTilePosBits <= 32, "tile positions must fit the key");
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); } // v_min3_u32
+__device__ __forceinline__ void window_minima_17(const uint32_t *keys, uint32_t t, uint32_t (&out)[4]) {
+    uint32_t x[20];
+    const uint4 *v = reinterpret_cast<const uint4 *>(keys + 4 * t);
+#pragma unroll
+    for (int a = 0; a < 5; ++a) { const uint4 q = v[a]; x[4 * a] = q.x; x[4 * a + 1] = q.y; x[4 * a + 2] = q.z; x[4 * a + 3] = q.w; }
+    uint32_t mid = min3u(x[3], x[4], x[5]); // keys 3 .. 16, shared by the four windows
+    mid = min3u(mid, x[6], x[7]);
+    mid = min3u(mid, x[8], x[9]);
+    mid = min3u(mid, x[10], x[11]);
+    mid = min3u(mid, x[12], x[13]);
+    mid = min3u(mid, x[14], x[15]);
+    mid = min(mid, x[16]);
+    out[0] = min(min3u(x[0], x[1], x[2]), mid);
+    out[1] = min(min3u(x[1], x[2], x[17]), mid);
+    out[2] = min(min3u(x[2], x[17], x[18]), mid);
+    out[3] = min(min3u(x[17], x[18], x[19]), mid);
 }
 
 // Every window is an independent lookup through the tile machinery (the loop of bin/kphf/main.rs:314-324).
@@ -1129,12 +1155,27 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
         }
         __syncthreads();
         // w-mer hashes of the tile, both strands
+        constexpr bool kPackedKeys = KW == kKW3115; // single 32-bit keys and the shared-span sliding minimum (window_minima_17)
         for (uint32_t j = t; j < kTileQ + n_win - 1; j += kBlock) {
             const uint64_t m = tile_mer(R, j, w);
-            R.hf[j] = (H)hash_mmer(m, ix.seed, w);
-            R.hr[j] = (H)hash_mmer(kmer_rc(m, w), ix.seed, w);
+            if constexpr (kPackedKeys) {
+                R.hf[j] = (H)((hash_mmer32((uint32_t)m, ix.seed) << kTilePosBits) | j);
+                R.hr[j] = (H)((hash_mmer32((uint32_t)kmer_rc(m, w), ix.seed) << kTilePosBits) | ((1u << kTilePosBits) - 1 - j));
+            } else {
+                R.hf[j] = (H)hash_mmer(m, ix.seed, w);
+                R.hr[j] = (H)hash_mmer(kmer_rc(m, w), ix.seed, w);
+            }
         }
         __syncthreads();
+        if constexpr (kPackedKeys) { // window minima in place: every key is read before any is overwritten
+            uint32_t wf[4], wr[4];
+            window_minima_17(reinterpret_cast<const uint32_t *>(R.hf), t, wf);
+            window_minima_17(reinterpret_cast<const uint32_t *>(R.hr), t, wr);
+            __syncthreads();
+            *reinterpret_cast<uint4 *>(&R.hf[4 * t]) = uint4{wf[0], wf[1], wf[2], wf[3]};
+            *reinterpret_cast<uint4 *>(&R.hr[4 * t]) = uint4{wr[0], wr[1], wr[2], wr[3]};
+            __syncthreads();
+        }
         // S0: one item per base position
         uint64_t out_idx[kQpt];
         uint32_t state[kQpt]; // 0 = no window here, 1 = window with a non-ACGT byte, 2 = valid k-mer (answer pending)
@@ -1168,7 +1209,13 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
             if (query) {
                 fw = tile_mer(R, i, k);
                 rc = kmer_rc(fw, k);
-                if (query) mn = window_minimizer(R, i, fw, rc, k, w);
+                if constexpr (kPackedKeys) { // minimum key of the window -> offset of the minimizer inside g*
+                    const uint32_t key = fw <= rc ? (uint32_t)R.hf[i] : (uint32_t)R.hr[i], low = key & ((1u << kTilePosBits) - 1);
+                    mn.offset = fw <= rc ? low - i : (k - w) - ((1u << kTilePosBits) - 1 - low - i);
+                    mn.word = ((fw <= rc ? fw : rc) >> (2 * mn.offset)) & kmer_mask(w);
+                } else {
+                    mn = window_minimizer(R, i, fw, rc, k, w);
+                }
             }
             tile_set_query<SC>(S, it, fw, rc, mn, k, w, query, ix.front.lines != nullptr);
             if (state[q] == 1) { // non-ACGT window: reported, never queried

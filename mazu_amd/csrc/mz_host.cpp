@@ -947,7 +947,7 @@ uint64_t SSHashHost::num_bits() const { // from the scalars: the arrays may stil
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '1', '1'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '1', '2'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>

@@ -157,7 +157,7 @@ class FlatIndexFile:
 
     def __init__(self, data):
         self.d = bytearray(data)
-        assert bytes(self.d[:8]) == b"MZSSH011"
+        assert bytes(self.d[:8]) == b"MZSSH012"
         o = 8
         self.k, self.w = struct.unpack_from("<II", self.d, o); o += 8
         self.seed, self.skew_param, self.total_len, self.n_unitigs, self.n_minimizers = struct.unpack_from("<5Q", self.d, o); o += 40
