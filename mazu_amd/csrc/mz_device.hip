@@ -1077,16 +1077,25 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
     const uint64_t tile_begin_wg = (uint64_t)blockIdx.x * tiles_per_wg, tile_end_wg = tile_begin_wg + tiles_per_wg < n_tiles ? tile_begin_wg + tiles_per_wg : n_tiles;
     uint64_t next_read0 = ~0ull; // wave 0: read0 of the next tile when it is known, else ~0 (search)
     Tally tally;
+    // the bases of a tile (kQpt x 256 positions + the k-1 tail, read by wave 1) are requested one tile ahead: the loads of
+    // tile + 1 are in flight while the lookups of tile run
+    uint32_t code[kQpt], tail_code = (uint32_t)'N';
+    auto request_bases = [&](uint64_t tile_) {
+        const uint64_t B = tile_ * kTileQ;
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            const uint64_t b = B + (uint64_t)q * kBlock + t;
+            code[q] = b < n_bases ? bases[b] : (uint32_t)'N';
+        }
+        const uint64_t bt = B + kTileQ + lane;
+        tail_code = (wave == 1 && lane < k - 1 && bt < n_bases) ? bases[bt] : (uint32_t)'N';
+    };
+    if (tile_begin_wg < tile_end_wg) request_bases(tile_begin_wg);
     for (uint64_t tile = tile_begin_wg; tile < tile_end_wg; ++tile) {
         const uint64_t B0 = tile * kTileQ;
         tile_begin<SC>(S);
-        // stage the bit planes: kQpt x 256 positions (one ballot triple per wave and slice) + the k-1 tail
-        uint32_t code[kQpt];
-#pragma unroll
-        for (int q = 0; q < kQpt; ++q) { // the loads first: wave 0 looks the reads up while they are in flight
-            const uint64_t b = B0 + (uint64_t)q * kBlock + t;
-            code[q] = b < n_bases ? bases[b] : (uint32_t)'N';
-        }
+        // stage the bit planes: one ballot triple per wave and slice of 256 positions (wave 0 looks the reads up first, while
+        // the bases of the first tile are still in flight)
         if (wave == 0) {
             // read holding the first base of the tile: largest r with read_offsets[r] <= B0.  Carried over from the previous tile,
             // else a 64-ary search (every lane probes one offset per round)
@@ -1138,8 +1147,7 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
             if (lane == 0) { uint32_t wi = q * (kBlock / 64) + wave; R.plane_lo[wi] = blo; R.plane_hi[wi] = bhi; R.plane_inv[wi] = binv; }
         }
         if (wave == 1) {
-            uint64_t bt = B0 + kTileQ + lane;
-            uint32_t ct = (lane < k - 1 && bt < n_bases) ? base_code_dev(bases[bt]) : 4u;
+            const uint32_t ct = base_code_dev((uint8_t)tail_code);
             unsigned long long tlo = __ballot(ct & 1u), thi = __ballot((ct >> 1) & 1u), tinv = __ballot(ct >> 2);
             if (lane == 0) {
                 R.plane_lo[kTileQ / 64] = tlo; R.plane_hi[kTileQ / 64] = thi; R.plane_inv[kTileQ / 64] = tinv;
@@ -1147,6 +1155,7 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
             }
         }
         __syncthreads();
+        if (tile + 1 < tile_end_wg) request_bases(tile + 1);
         // the tile 2-bit packed: word j = bases [32 j, 32 j + 32) from the low / high code bit planes
         if (t < kTileQ / 32 + 4) {
             const uint32_t half = 32 * (t & 1);
