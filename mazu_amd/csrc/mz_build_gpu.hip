@@ -674,6 +674,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
             buf.give(d_lines_keep, d, h.front.n_words(w) * 8);
         }
         d->view = v;
+        d->n_entries = h.pos.n;
         *keep = d;
     }
     h.build_seconds = now_s() - t_begin;

@@ -1421,6 +1421,7 @@ int device_upload(const SSHashHost &h, int device, DeviceIndex **out) {
         if ((rc = upload(d, h.front.lines.data(), h.front.lines.size(), &v.front.lines)) != MZ_OK) return fail(rc);
     }
     d->view = v;
+    d->n_entries = h.pos.n;
     *out = d;
     return MZ_OK;
 }
@@ -1520,11 +1521,19 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
     MZ_HIP_CHECK(hipSetDevice(d.device));
     const dim3 grid(tile_grid(d, (n_bases + kTileQ - 1) / kTileQ, 8));
     (void)streaming; // same kernel: see the note above k2u_reads_kernel
-    if (d.view.k == 31 && d.view.w == 15)
-        hipLaunchKernelGGL(k2u_reads_kernel<kKW3115>, grid, dim3(kBlock), 0, stream, d.view, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
+    // The windows of a read share their minimizer for ~9 positions.  Through the minimizer records one lookup serves a whole
+    // run of windows; through the minimizer lines every window fetches its line (mostly from the caches).  Measured: the
+    // records win while records + entries stay cache-friendly (s-txome, 60 M entries: 22.8 against 20.5 G windows/s), the
+    // lines win on large indexes (S-human, 547 M entries: 16.2 against 15.2).  MZ_READS_LINES=0/1 overrides the rule.
+    IndexView v = d.view;
+    const char *lines_env = getenv("MZ_READS_LINES");
+    const bool use_lines = lines_env ? lines_env[0] != '0' : d.n_entries >= (1ull << 28);
+    if (!use_lines && v.mm.direct) v.front.lines = nullptr;
+    if (v.k == 31 && v.w == 15)
+        hipLaunchKernelGGL(k2u_reads_kernel<kKW3115>, grid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
                            n_reads, d_out, d_counts);
     else
-        hipLaunchKernelGGL(k2u_reads_kernel<0>, grid, dim3(kBlock), 0, stream, d.view, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
+        hipLaunchKernelGGL(k2u_reads_kernel<0>, grid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
                            n_reads, d_out, d_counts);
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;

@@ -16,6 +16,7 @@ struct DeviceIndex {
     std::vector<void *> allocs; // everything hipMalloc'ed for this replica
     uint64_t bytes = 0;
     uint32_t n_cu = 256;
+    uint64_t n_entries = 0;    // bucket entries of the index (size of `pos`)
 };
 
 // restores the caller's current HIP device when an entry point that switched devices returns

@@ -72,18 +72,22 @@ def test_s_eighth_headline_kernel_matches_oracle(monkeypatch, front):
     assert abs(n_hit - 1_200_000) <= 8  # positives hit; NEG-U / NEG-1 negatives miss (up to accidental members)
 
 
-@pytest.mark.parametrize("bytes_per_key,kind", [("48", 1), ("16", 0)])
-def test_s_txome_reads_match_oracle_streaming_walk(monkeypatch, bytes_per_key, kind):
+@pytest.mark.parametrize("bytes_per_key,kind,reads_lines", [("48", 1, None), ("48", 1, "1"), ("16", 0, None)])
+def test_s_txome_reads_match_oracle_streaming_walk(monkeypatch, bytes_per_key, kind, reads_lines):
     """BASELINE configs[2] shape: 150-bp reads over a 145 Mbp, 1.2 M-unitig set, requested as .as_streaming();
     every window must equal the oracle's StreamingK2U walk (index/caching.rs:65-103, bin/kphf/main.rs:299-312).
-    Once with the direct-address minimizer records the size rule picks for this set, once with the BBHash levels it
-    picks for smaller ones (the reads kernel resolves one minimizer per run of windows through either)."""
+    Once with the direct-address minimizer records the size rule picks for this set (the reads kernel then resolves one
+    minimizer per run of windows through the records, although the index also has minimizer lines), once through the
+    minimizer lines (what the kernel does on large indexes), once with the BBHash levels the rule picks for smaller sets."""
     import torch
     from mazu_amd import synth
     monkeypatch.setenv("MZ_DIRECT_BYTES_PER_KEY", bytes_per_key)
+    if reads_lines is not None:
+        monkeypatch.setenv("MZ_READS_LINES", reads_lines)
     us = synth.make_unitig_set("s-txome", device="cuda")
     ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
     assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and ix.minimizer_mphf_kind() == kind
+    assert ix.has_minimizer_lines() == (kind == 1)
     n_reads, read_len = 20_000, 150
     bases, ro = synth.make_reads(us, n_reads, read_len, seed=2000, device="cuda")
     ko = synth.kmer_offsets(ro, 31)
