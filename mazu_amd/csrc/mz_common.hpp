@@ -386,7 +386,10 @@ MZ_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 //   bits 28..63 kind 0: minimizer position; kind 2: first entry of the bucket in the entry array
 // Slots are in key order, the entries of a key in bucket order.  Every member key owns at least one slot (2^g <= 16), so
 // a key with no slot is not a minimizer of the set.  Which buckets go inline is decided per line by front_build_line().
-constexpr uint32_t kFrontSlots = 16, kFrontMaxG = 4, kFrontKindBits = 2, kFrontKeyShift = 2, kFrontKeyBits = 9, kFrontFlankShift = 11,
+#ifndef MZ_FRONT_SLOTS
+#define MZ_FRONT_SLOTS 16 // slots per line: 16 (128-byte lines; 8 = 64-byte lines measured 7 % slower at S-human: a line load of 2 of 8 slots spills 14 % of the entry mass); builders and kernels must agree
+#endif
+constexpr uint32_t kFrontSlots = MZ_FRONT_SLOTS, kFrontMaxG = kFrontSlots == 16 ? 4 : 3, kFrontKindBits = 2, kFrontKeyShift = 2, kFrontKeyBits = 9, kFrontFlankShift = 11,
                    kFrontClsShift = 27, kFrontPosShift = 28;
 constexpr uint32_t kFrontEntry = 0, kFrontHeavy = 1, kFrontSpill = 2, kFrontEmptyKind = 3;
 constexpr uint64_t kFrontEmpty = ~0ull;
@@ -538,10 +541,10 @@ constexpr uint64_t kFrontFreeBytes = 9ull << 30;
 MZ_HD int front_choose_g(uint32_t w, uint64_t n_occ) {
     if (2 * w > 32) return -1;
     const uint64_t cap = 40 * n_occ > kFrontFreeBytes ? 40 * n_occ : kFrontFreeBytes;
-    for (uint64_t max_load = 5; max_load <= 10; max_load += 5)
+    for (uint64_t max_load16 = 5; max_load16 <= 10; max_load16 += 5) // mean load allowed, in sixteenths of the line's slots
         for (int g = (int)(2 * w < kFrontMaxG ? 2 * w : kFrontMaxG); g >= 0; --g) {
             const uint64_t n_lines = 1ull << (2 * w - g);
-            if (n_occ > max_load * n_lines) continue;
+            if (16 * n_occ > max_load16 * kFrontSlots * n_lines) continue;
             if (n_lines * kFrontSlots * 8 <= cap) return g;
             break; // smaller g only makes the table larger
         }

@@ -352,23 +352,24 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
 #define MZ_SF_BATCH 8
 #endif
         constexpr int kFR = MZ_SF_BATCH;                       // rounds (of 8 queries) whose lines are in flight together
-        constexpr uint32_t kRounds = 64 * kQpt / 8;            // per wavefront: 8 queries per 64 lanes and round
-        const uint32_t lane = t & 63, sub = lane & 7, grp = lane >> 3, g = ix.front.g;
+        constexpr uint32_t kLpq = kFrontSlots / 2, kQpr = 64 / kLpq; // lanes per query (two slots each), queries per round
+        constexpr uint32_t kRounds = 64 * kQpt / kQpr;          // per wavefront
+        const uint32_t lane = t & 63, sub = lane % kLpq, grp = lane / kLpq, g = ix.front.g;
         const uint32_t wave_q0 = (t >> 6) * (64 * kQpt);      // first item of this wave's share of the tile
-        const unsigned long long grp_mask = 0xFFull << (lane & ~7u), low_mask = grp_mask & ((1ull << lane) - 1); // my query's lanes / those before me
+        const unsigned long long grp_mask = ((1ull << kLpq) - 1) << (lane & ~(kLpq - 1)), low_mask = grp_mask & ((1ull << lane) - 1); // my query's lanes / those before me
         for (uint32_t r0 = 0; r0 < kRounds; r0 += kFR) { // (a rolling window of requests instead of batches measured the same: the gathers are bandwidth-bound)
             ulonglong2 sl[kFR];
             uint32_t pat[kFR];
 #pragma unroll
             for (int a = 0; a < kFR; ++a) { // all loads of the batch first
-                const uint64_t kp = S.slot[wave_q0 + (r0 + a) * 8 + grp];     // key | pattern << 32 (an idle slot has key 0: line 0 is always there)
+                const uint64_t kp = S.slot[wave_q0 + (r0 + a) * kQpr + grp];     // key | pattern << 32 (an idle slot has key 0: line 0 is always there)
                 const uint32_t key = (uint32_t)kp;
                 pat[a] = (uint32_t)(kp >> 32) | ((key & ((1u << g) - 1)) << kFrontKeyShift);
                 sl[a] = *reinterpret_cast<const ulonglong2 *>(ix.front.lines + (uint64_t)(key >> g) * kFrontSlots + 2 * sub);
             }
 #pragma unroll
             for (int a = 0; a < kFR; ++a) {
-                const uint32_t q = wave_q0 + (r0 + a) * 8 + grp, msk = S.eoff[q];
+                const uint32_t q = wave_q0 + (r0 + a) * kQpr + grp, msk = S.eoff[q];
                 const uint64_t e0 = sl[a].x, e1 = sl[a].y;
                 const uint32_t x0 = (uint32_t)e0 ^ pat[a], x1 = (uint32_t)e1 ^ pat[a];
                 const bool s0 = (x0 & msk) == 0, s1 = (x1 & msk) == 0; // an entry (kind 0) of this key whose flanks agree

@@ -715,17 +715,17 @@ int FrontTable::choose_g(uint32_t w, uint64_t n_occ, bool direct) {
     if (!direct) return -1; // the lines are addressed by key and built from the minimizer records
     const char *e = std::getenv("MZ_FRONT_TABLE");
     if (e && e[0] == '0') return -1;
-    if (e && e[0] == '1') { // forced: the largest g that keeps the mean load at or under 10 slots, whatever the table size
+    if (e && e[0] == '1') { // forced: the largest g that keeps the mean load at or under 10/16 of the slots, whatever the table size
         if (2 * w > 32) return -1;
         for (int g = (int)std::min<uint32_t>(2 * w, kFrontMaxG); g >= 0; --g)
-            if (n_occ <= 10 * (1ull << (2 * w - g))) return g;
+            if (16 * n_occ <= 10 * kFrontSlots * (1ull << (2 * w - g))) return g;
         return -1;
     }
-    if (const char *l = std::getenv("MZ_FRONT_MAX_LOAD")) { // experiments: mean slots per line allowed (front_choose_g prefers 5 and accepts 10)
+    if (const char *l = std::getenv("MZ_FRONT_MAX_LOAD")) { // experiments: mean line load allowed, in sixteenths of the slots (front_choose_g prefers 5 and accepts 10)
         const double load = std::atof(l);
         if (load > 0 && 2 * w <= 32)
             for (int g = (int)std::min<uint32_t>(2 * w, kFrontMaxG); g >= 0; --g)
-                if ((double)n_occ <= load * (double)(1ull << (2 * w - g))) return g;
+                if ((double)n_occ * 16.0 <= load * kFrontSlots * (double)(1ull << (2 * w - g))) return g;
     }
     return front_choose_g(w, n_occ);
 }
