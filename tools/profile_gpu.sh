@@ -18,9 +18,10 @@ echo "pass stats" >&2
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -o trace -- $BENCH > "$RAW/stats.json" 2> "$RAW/stats.err" || echo "stats failed rc=$?"
 run_pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 run_pmc sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU
-run_pmc fetch FETCH_SIZE GRBM_GUI_ACTIVE
+run_pmc fetch FETCH_SIZE TCC_REQ_sum GRBM_GUI_ACTIVE
 run_pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-run_pmc tcc TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+run_pmc tcc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+run_pmc lat TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum
 {
   echo "command: bash tools/profile_gpu.sh $W $TAG $STEPS $EXTRA   (separate rocprofv3 passes)"
   echo "bench line under --kernel-trace: $(tail -1 "$RAW/stats.json" | cut -c1-400)"
