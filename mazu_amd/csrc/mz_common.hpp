@@ -533,14 +533,18 @@ MZ_HD uint32_t front_line_members(const uint64_t *minrec, uint32_t g, uint64_t l
     return (uint32_t)((wv >> bi) & ((1ull << (1u << g)) - 1)); // 2^g <= 16 keys never straddle a bitmap word
 }
 // g for a key universe of 2^(2w) and n_occ entries, or -1 when minimizer lines do not pay.  The table must stay within
-// max(9 GiB, 40 bytes per entry): one MI355X holds 288 GB, and for a set of transcriptome size the 8.6 GB table of w = 15
-// buys a fifth more point-query throughput than the minimizer records alone.  Preferred: the largest g <= 4 with a mean line
-// load of at most 5 of the 16 slots (about 94 % of the entry mass then sits inline and 3 % spills); if that table is too
-// large, the largest g with a load of at most 10 (88 % inline, 9 % spilled).
-constexpr uint64_t kFrontFreeBytes = 9ull << 30;
+// max(64 MiB, 40 bytes per entry, min(9 GiB, 1 KiB per entry)): one MI355X holds 288 GB, and for a set of transcriptome
+// size the 8.6 GB table of w = 15 buys a fifth more point-query throughput than the minimizer records alone, while a tiny
+// set does not get a table thousands of times its own size.  Preferred: the largest g <= 4 with a mean line load of at most
+// 5 of the 16 slots (about 94 % of the entry mass then sits inline and 3 % spills); if that table is too large, the largest
+// g with a load of at most 10 (88 % inline, 9 % spilled).
+constexpr uint64_t kFrontFreeBytes = 9ull << 30, kFrontFreeBytesPerEntry = 1024;
 MZ_HD int front_choose_g(uint32_t w, uint64_t n_occ) {
     if (2 * w > 32) return -1;
-    const uint64_t cap = 40 * n_occ > kFrontFreeBytes ? 40 * n_occ : kFrontFreeBytes;
+    uint64_t cap = 64ull << 20;
+    if (40 * n_occ > cap) cap = 40 * n_occ;
+    const uint64_t free_cap = kFrontFreeBytesPerEntry * n_occ < kFrontFreeBytes ? kFrontFreeBytesPerEntry * n_occ : kFrontFreeBytes;
+    if (free_cap > cap) cap = free_cap;
     for (uint64_t max_load16 = 5; max_load16 <= 10; max_load16 += 5) // mean load allowed, in sixteenths of the line's slots
         for (int g = (int)(2 * w < kFrontMaxG ? 2 * w : kFrontMaxG); g >= 0; --g) {
             const uint64_t n_lines = 1ull << (2 * w - g);
