@@ -25,9 +25,19 @@ __global__ __launch_bounds__(256) void gather(const uint64_t *__restrict__ buf, 
             const uint64_t *p = buf + line * 8 + ((s >> 60) & 6);
             if (BYTES == 8) v[j] = p[0];
             else if (BYTES == 16) { ulonglong2 t = *(const ulonglong2 *)p; v[j] = t.x ^ t.y; }
-            else { // BYTES == 128: touch both 64-byte halves of one 128-byte aligned pair (counts as ONE gather)
+            else if (BYTES == 128) { // touch both 64-byte halves of one 128-byte aligned pair with TWO loads (counts as ONE gather)
                 const uint64_t *q = buf + (line & ~1ull) * 8;
                 v[j] = q[0] ^ q[8];
+            } else if (BYTES == 1280) { // the line-scan pattern: eight lanes share one random 128-byte line, ONE 16-byte load each
+                const uint64_t gs = mix(((tid >> 3) + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)it * ILP + j);
+                const uint64_t l2 = (uint64_t)(((__uint128_t)gs * (n_lines / 2)) >> 64);
+                ulonglong2 t = *(const ulonglong2 *)(buf + l2 * 16 + 2 * (tid & 7));
+                v[j] = t.x ^ t.y;
+            } else { // BYTES == 64: the record pattern: every lane reads its own random 64-byte record with 2 x 8 + 2 x 16 byte loads
+                const uint64_t *q = buf + line * 8;
+                const unsigned o = (unsigned)(s >> 57) & 2u;
+                ulonglong2 t0 = *(const ulonglong2 *)(q + 4), t1 = *(const ulonglong2 *)(q + 6);
+                v[j] = q[o] ^ q[o + 1] ^ t0.x ^ t0.y ^ t1.x ^ t1.y;
             }
         }
 #pragma unroll
@@ -38,7 +48,7 @@ __global__ __launch_bounds__(256) void gather(const uint64_t *__restrict__ buf, 
 
 template <int ILP, int BYTES, bool DEP>
 static void run(const uint64_t *buf, uint64_t n_lines, uint64_t *out, int blocks, const char *name) {
-    int iters = 64 / ILP * 4;
+    int iters = 64 / ILP * 4 * (BYTES == 1280 ? 4 : 1);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     hipLaunchKernelGGL((gather<ILP, BYTES, DEP>), dim3(blocks), dim3(256), 0, 0, buf, n_lines, iters, out);
@@ -49,7 +59,7 @@ static void run(const uint64_t *buf, uint64_t n_lines, uint64_t *out, int blocks
     hipEventSynchronize(b);
     float ms = 0;
     hipEventElapsedTime(&ms, a, b);
-    double loads = (double)blocks * 256 * iters * ILP;
+    double loads = (double)blocks * 256 * iters * ILP / (BYTES == 1280 ? 8 : 1);
     printf("%-28s blocks=%6d  %7.2f G lines/s  = %6.2f TB/s of 64-B lines  (%.3f ms)\n", name, blocks, loads / ms / 1e6, loads * 64 / ms / 1e9, ms);
 }
 
@@ -68,6 +78,8 @@ int main(int argc, char **argv) {
         run<8, 8, false>(buf, n_lines, out, blocks, "ILP8 8 B");
         run<4, 16, false>(buf, n_lines, out, blocks, "ILP4 16 B");
         run<4, 128, false>(buf, n_lines, out, blocks, "ILP4 2x64B adjacent (pairs/s)");
+        run<8, 1280, false>(buf, n_lines, out, blocks, "ILP8 8 lanes x 16 B = one 128-B line");
+        run<2, 64, false>(buf, n_lines, out, blocks, "ILP2 64-B record, 4 loads per lane");
     }
     return 0;
 }
