@@ -657,12 +657,16 @@ static void scan_unitig(const uint64_t *useq, uint64_t s, uint64_t e, uint32_t k
     }
 }
 
+// Direct-address minimizer records (one 128-byte record per 256 possible w-mers) instead of BBHash levels: when the record
+// table stays within max(64 MiB, 48 bytes per key, min(1 GiB, 1 KiB per key)).  The last term spends up to 1 GiB of the
+// 288 GB on sets of half a million minimizers and more (a yeast-sized set at w = 15: 0.54 GB of records, 25.0 against
+// 18.4 G k-mers/s through the BBHash levels); MZ_DIRECT_BYTES_PER_KEY replaces the rule by "at most that many bytes per key".
 bool use_direct_records(uint32_t w, uint64_t n_mm) {
     if (2 * w > 32) return false;
-    uint64_t per_key = 48;
-    if (const char *e = getenv("MZ_DIRECT_BYTES_PER_KEY")) per_key = strtoull(e, nullptr, 10);
     const uint64_t rec_bytes = (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords * 8;
-    return rec_bytes <= std::max<uint64_t>(64ull << 20, per_key * n_mm);
+    if (const char *e = getenv("MZ_DIRECT_BYTES_PER_KEY")) return rec_bytes <= std::max<uint64_t>(64ull << 20, strtoull(e, nullptr, 10) * n_mm);
+    const uint64_t free_cap = std::min<uint64_t>(1ull << 30, 1024 * n_mm);
+    return rec_bytes <= std::max<uint64_t>(std::max<uint64_t>(64ull << 20, 48 * n_mm), free_cap);
 }
 uint32_t skew_fp_bits_for_build() {
     if (const char *e = std::getenv("MZ_TEST_SKEW_FP_BITS")) {
