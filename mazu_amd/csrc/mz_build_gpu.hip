@@ -269,15 +269,14 @@ __global__ __launch_bounds__(kB) void pos_entries_kernel(const uint64_t *__restr
     }
 }
 
-// minimizer lines (FrontTable::build of the host): one lane per line
-__global__ __launch_bounds__(kB) void front_lines_kernel(const uint64_t *__restrict__ minrec, uint32_t g, uint64_t n_lines, const uint64_t *__restrict__ psum,
-                                                         const uint64_t *__restrict__ entries, uint64_t skew_param, uint64_t *__restrict__ lines) {
-    uint64_t stride = (uint64_t)gridDim.x * kB;
+// minimizer lines (FrontTable::build of the host): one lane per line; *overfull is raised when a line has more than 16 member keys
+__global__ __launch_bounds__(kB) void front_lines_kernel(const uint64_t *__restrict__ minrec, uint32_t g, uint32_t t, uint32_t line_bits,
+                                                         const uint64_t *__restrict__ psum, const uint64_t *__restrict__ entries, uint64_t skew_param,
+                                                         uint64_t *__restrict__ lines, unsigned long long *overfull) {
+    const uint64_t n_lines = 1ull << line_bits, stride = (uint64_t)gridDim.x * kB;
     for (uint64_t line = (uint64_t)blockIdx.x * kB + threadIdx.x; line < n_lines; line += stride) {
-        uint64_t bucket0;
-        const uint32_t members = front_line_members(minrec, g, line, bucket0);
         uint64_t out[kFrontSlots];
-        front_build_line(g, members, bucket0, psum, entries, skew_param, out);
+        if (!front_build_line(g, t, line_bits, line, minrec, psum, entries, skew_param, out)) *overfull = 1ull; // (any number of lanes may raise it)
 #pragma unroll
         for (uint32_t q = 0; q < kFrontSlots; ++q) lines[line * kFrontSlots + q] = out[q];
     }
@@ -538,22 +537,32 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
             if (int rc = download(h.mm.blocks, d_minrec, n_rec * kMinRecWords)) return rc;
         }
         // minimizer lines from the finished records, bucket starts and entries
-        const int fg = FrontTable::choose_g(w, n_occ, true);
-        h.front.present = fg >= 0;
         h.front.lines.clear();
-        if (fg >= 0) {
-            h.front.g = (uint32_t)fg;
-            const uint64_t n_lines = 1ull << (2 * w - fg);
+        h.front.present = FrontTable::choose(w, n_occ, true, h.front.g, h.front.t);
+        while (h.front.present) {
+            const uint32_t line_bits = 2 * w - h.front.g - h.front.t;
+            const uint64_t n_lines = 1ull << line_bits;
             uint64_t *d_lines = nullptr;
             BG_HIP(buf.alloc(&d_lines, n_lines * kFrontSlots));
-            hipLaunchKernelGGL(front_lines_kernel, dim3(grid_of(n_lines)), dim3(kB), 0, 0, d_minrec, (uint32_t)fg, n_lines, d_psum, d_packed, skew_param, d_lines);
+            BG_HIP(hipMemset(d_counter, 0, 8));
+            hipLaunchKernelGGL(front_lines_kernel, dim3(grid_of(n_lines)), dim3(kB), 0, 0, d_minrec, h.front.g, h.front.t, line_bits, d_psum, d_packed, skew_param,
+                               d_lines, d_counter);
             BG_HIP(hipGetLastError());
+            unsigned long long overfull = 0;
+            BG_HIP(hipMemcpy(&overfull, d_counter, 8, hipMemcpyDeviceToHost));
+            if (overfull) { // some line has more than 16 member keys: fold the key space less (as the host builder does)
+                buf.release(d_lines);
+                h.front.present = FrontTable::next_shape(w, n_occ, h.front.g, h.front.t);
+                continue;
+            }
             if (!resident) {
                 if (int rc = download(h.front.lines, d_lines, n_lines * kFrontSlots)) return rc;
                 buf.release(d_lines);
             }
             d_lines_keep = d_lines;
+            break;
         }
+        if (!h.front.present) h.front.g = h.front.t = 0;
         d_packed_keep = d_packed;
         d_minrec_keep = d_minrec;
         if (!resident) {
@@ -670,7 +679,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         }
         v.front = h.front.view();
         if (h.front.present) {
-            v.front = FrontView{d_lines_keep, (uint64_t)1 << (2 * w - h.front.g), h.front.g, 0};
+            v.front = FrontView{d_lines_keep, (uint64_t)1 << (2 * w - h.front.g - h.front.t), h.front.g, h.front.t};
             buf.give(d_lines_keep, d, h.front.n_words(w) * 8);
         }
         d->view = v;

@@ -374,31 +374,35 @@ MZ_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 }
 
 // ---- minimizer lines ("front table") ------------------------------------------------------------------------------
-// For w-mers with 2w <= 32 the bucket entries of 2^g consecutive keys (g <= 4) live in ONE 128-byte line of 16 slots,
-// addressed directly by key >> g: a query learns membership, its bucket's entries and their flank fingerprints from a
-// single gather, where the reference probes an MPHF, two Elias-Fano offsets and then the position array
-// (sshash.rs:478-495).  Slot (64 bits):
+// For w-mers with 2w <= 32 the bucket entries of a group of minimizer words live in ONE 128-byte line of 16 slots that is
+// addressed directly by bits of the word -- no hash, no probing: a query learns membership, its bucket's entries and their
+// flank fingerprints from a single gather, where the reference probes an MPHF, two Elias-Fano offsets and then the
+// position array (sshash.rs:478-495).  A word is cut into  tag (t bits) | line index (L bits) | low (g bits),  2w = t + L + g:
+// line = (word >> g) mod 2^L, and the slot carries low | tag << g so that the 2^(g+t) words that share a line are told
+// apart.  g + t <= 8, g <= 4; t = 0 is "2^g consecutive words per line"; t > 0 folds the key space so that the table of a
+// small set has as many lines as its entries need, not 4^w / 16.  Slot (64 bits):
 //   bits 0..1   kind: 0 = bucket entry, 1 = the key's bucket is heavy (answered by the skew index, sshash.rs:486-490),
 //               2 = the key's bucket did not fit the line (payload: its range in the entry array), 3 = empty slot
-//   bits 2..10  key & (2^g - 1) (9-bit field)
+//   bits 2..10  low | tag << g (9-bit field, at most 8 bits in use: the all-ones field of an empty slot matches no word)
 //   bits 11..26 kind 0: flank16 of the occurrence in the orientation of the canonical k-mer; kind 2: bucket size (saturated)
 //   bit  27     kind 0: strand class of the occurrence
 //   bits 28..63 kind 0: minimizer position; kind 2: first entry of the bucket in the entry array
-// Slots are in key order, the entries of a key in bucket order.  Every member key owns at least one slot (2^g <= 16), so
-// a key with no slot is not a minimizer of the set.  Which buckets go inline is decided per line by front_build_line().
-#ifndef MZ_FRONT_SLOTS
-#define MZ_FRONT_SLOTS 16 // slots per line: 16 (128-byte lines; 8 = 64-byte lines measured 7 % slower at S-human: a line load of 2 of 8 slots spills 14 % of the entry mass); builders and kernels must agree
-#endif
-constexpr uint32_t kFrontSlots = MZ_FRONT_SLOTS, kFrontMaxG = kFrontSlots == 16 ? 4 : 3, kFrontKindBits = 2, kFrontKeyShift = 2, kFrontKeyBits = 9, kFrontFlankShift = 11,
+// The entries of a key are in bucket order.  Every member key owns at least one slot, so a key with no slot in its line
+// is not a minimizer of the set; a table in which some line has more than 16 member keys is not used (the builders then
+// halve t and build again; t = 0 cannot overflow).  Which buckets go inline is decided per line by front_build_line().
+constexpr uint32_t kFrontSlots = 16, kFrontMaxG = 4, kFrontMaxKeyBits = 8, kFrontKindBits = 2, kFrontKeyShift = 2, kFrontKeyBits = 9, kFrontFlankShift = 11,
                    kFrontClsShift = 27, kFrontPosShift = 28;
 constexpr uint32_t kFrontEntry = 0, kFrontHeavy = 1, kFrontSpill = 2, kFrontEmptyKind = 3;
 constexpr uint64_t kFrontEmpty = ~0ull;
 constexpr uint32_t kFrontKeyMask = ((1u << kFrontKeyBits) - 1) << kFrontKeyShift;
 struct FrontView {
     const uint64_t *lines; // n_lines * 16 slots; nullptr: the index has no minimizer lines
-    uint64_t n_lines;
-    uint32_t g, pad;
+    uint64_t n_lines;      // 2^L
+    uint32_t g, t;
 };
+MZ_HD uint64_t front_line_of(uint32_t key, uint32_t g, uint64_t n_lines) { return (uint64_t)(key >> g) & (n_lines - 1); }
+// low | tag << g of a word; gl = g + L (<= 32)
+MZ_HD uint32_t front_keyfield(uint32_t key, uint32_t g, uint32_t gl) { return (key & ((1u << g) - 1)) | ((uint32_t)((uint64_t)key >> gl) << g); }
 struct IndexView {
     uint32_t k, w;
     uint64_t seed;
@@ -481,27 +485,49 @@ MZ_HD uint64_t front_marker_slot(uint32_t kind, uint32_t keylow, uint64_t first,
     const uint64_t c = count < 0xFFFFull ? count : 0xFFFFull;
     return (first << kFrontPosShift) | (c << kFrontFlankShift) | ((uint64_t)keylow << kFrontKeyShift) | kind;
 }
-// Packs one line.  member_bits: bit j set when key (line << g) + j is a minimizer; bucket0: bucket id of the first member
-// (bucket ids are ranks, so the members' buckets are bucket0, bucket0+1, ...); psum: bucket starts; entries: the entry
-// array (`pos` layout).  Light buckets are taken inline in order of increasing size (ties: key order) while every bucket
-// left out still keeps one slot for its marker.
-MZ_HD void front_build_line(uint32_t g, uint32_t member_bits, uint64_t bucket0, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param,
-                            uint64_t *out) {
-    uint32_t keylow[kFrontSlots], size_c[kFrontSlots];
+// the 2^g membership bits of the words (group << g) .. (group << g) + 2^g - 1 from the minimizer records, and the bucket id
+// of the first member among them (bucket ids are ranks, so the members' buckets are bucket0, bucket0 + 1, ...)
+MZ_HD uint32_t front_line_members(const uint64_t *minrec, uint32_t g, uint64_t group, uint64_t &bucket0) {
+    const uint64_t key0 = group << g;
+    const uint64_t *W = minrec + (key0 >> kMinRecKeysLog2) * kMinRecWords;
+    const uint32_t in_rec = (uint32_t)(key0 & ((1u << kMinRecKeysLog2) - 1)), j = in_rec >> 6, bi = in_rec & 63;
+    const uint64_t hdr = W[2 * j], wv = W[2 * j + 1];
+    bucket0 = (hdr & kMinRecRankMask) + (hdr >> 40) + popc64(wv & ~(~0ull << bi));
+    return (uint32_t)((wv >> bi) & ((1ull << (1u << g)) - 1)); // 2^g <= 16 keys never straddle a bitmap word
+}
+// Packs line `line` of a table with 2^line_bits lines.  minrec: the minimizer records (membership and bucket ids of the
+// 2^t groups of 2^g words that share the line); psum: bucket starts; entries: the entry array (`pos` layout).  Light buckets
+// are taken inline in order of increasing size (ties: member order) while every bucket left out still keeps one slot for
+// its marker.  Returns false, with the line left empty, when more than 16 member keys share the line.
+MZ_HD bool front_build_line(uint32_t g, uint32_t t, uint32_t line_bits, uint64_t line, const uint64_t *minrec, const uint64_t *psum,
+                            const uint64_t *entries, uint64_t skew_param, uint64_t *out) {
+    uint32_t keyfield[kFrontSlots], size_c[kFrontSlots];
     uint64_t first[kFrontSlots], size[kFrontSlots];
     bool inl[kFrontSlots];
     uint32_t m = 0;
-    for (uint32_t j = 0; j < (1u << g); ++j)
-        if ((member_bits >> j) & 1) {
-            keylow[m] = j;
-            first[m] = psum[bucket0 + m];
-            size[m] = psum[bucket0 + m + 1] - first[m];
-            size_c[m] = size[m] > skew_param || size[m] > kFrontSlots ? 0xFFFFFFFFu : (uint32_t)size[m]; // heavy or hopeless: never inline
-            inl[m] = false;
-            ++m;
-        }
+    bool overfull = false;
+    for (uint32_t tag = 0; tag < (1u << t) && !overfull; ++tag) {
+        uint64_t bucket0;
+        const uint32_t member_bits = front_line_members(minrec, g, line | ((uint64_t)tag << line_bits), bucket0);
+        uint32_t seen = 0;
+        for (uint32_t j = 0; j < (1u << g); ++j)
+            if ((member_bits >> j) & 1) {
+                if (m == kFrontSlots) { overfull = true; break; }
+                keyfield[m] = j | (tag << g);
+                first[m] = psum[bucket0 + seen];
+                size[m] = psum[bucket0 + seen + 1] - first[m];
+                size_c[m] = size[m] > skew_param || size[m] > kFrontSlots ? 0xFFFFFFFFu : (uint32_t)size[m]; // heavy or hopeless: never inline
+                inl[m] = false;
+                ++seen;
+                ++m;
+            }
+    }
+    if (overfull) {
+        for (uint32_t o = 0; o < kFrontSlots; ++o) out[o] = kFrontEmpty;
+        return false;
+    }
     uint32_t used = m; // one slot per member to begin with
-    for (;;) {         // repeatedly take the smallest bucket not yet inline (ties: lowest key)
+    for (;;) {         // repeatedly take the smallest bucket not yet inline (ties: first member)
         uint32_t best = kFrontSlots;
         for (uint32_t a = 0; a < m; ++a)
             if (!inl[a] && size_c[a] != 0xFFFFFFFFu && (best == kFrontSlots || size_c[a] < size_c[best])) best = a;
@@ -515,44 +541,42 @@ MZ_HD void front_build_line(uint32_t g, uint32_t member_bits, uint64_t bucket0, 
             for (uint64_t e = 0; e < size[a]; ++e) {
                 const uint64_t ent = entries[first[a] + e];
                 const uint32_t cls = (uint32_t)(ent >> 16) & 1u, fl = (uint32_t)(ent & 0xFFFFu);
-                out[o++] = front_entry_slot(ent >> 17, cls, cls ? flank_revcomp(fl) : fl, keylow[a]);
+                out[o++] = front_entry_slot(ent >> 17, cls, cls ? flank_revcomp(fl) : fl, keyfield[a]);
             }
         } else {
-            out[o++] = front_marker_slot(size[a] > skew_param ? kFrontHeavy : kFrontSpill, keylow[a], first[a], size[a]);
+            out[o++] = front_marker_slot(size[a] > skew_param ? kFrontHeavy : kFrontSpill, keyfield[a], first[a], size[a]);
         }
     }
     for (; o < kFrontSlots; ++o) out[o] = kFrontEmpty;
+    return true;
 }
-// the 2^g membership bits of line `line` from the minimizer records, and the bucket id of its first member
-MZ_HD uint32_t front_line_members(const uint64_t *minrec, uint32_t g, uint64_t line, uint64_t &bucket0) {
-    const uint64_t key0 = line << g;
-    const uint64_t *W = minrec + (key0 >> kMinRecKeysLog2) * kMinRecWords;
-    const uint32_t in_rec = (uint32_t)(key0 & ((1u << kMinRecKeysLog2) - 1)), j = in_rec >> 6, bi = in_rec & 63;
-    const uint64_t hdr = W[2 * j], wv = W[2 * j + 1];
-    bucket0 = (hdr & kMinRecRankMask) + (hdr >> 40) + popc64(wv & ~(~0ull << bi));
-    return (uint32_t)((wv >> bi) & ((1ull << (1u << g)) - 1)); // 2^g <= 16 keys never straddle a bitmap word
+// Shape of the table for a key universe of 2^(2w) words and n_occ entries: the fewest lines (a power of two, at least
+// 4^w / 256) that keep the mean line load at or under max_load entries; g = as many of the shared-line bits as fit the low
+// part (<= 4), the rest is tag.  Returns false when 2w > 32.
+MZ_HD bool front_shape_for_load(uint32_t w, uint64_t n_occ, uint64_t max_load, uint32_t &g, uint32_t &t) {
+    if (2 * w > 32) return false;
+    const uint32_t u = 2 * w, min_bits = u > kFrontMaxKeyBits ? u - kFrontMaxKeyBits : 0;
+    uint32_t line_bits = min_bits;
+    while (line_bits < u && n_occ > max_load * (1ull << line_bits)) ++line_bits;
+    g = u - line_bits < kFrontMaxG ? u - line_bits : kFrontMaxG;
+    t = u - line_bits - g;
+    return true;
 }
-// g for a key universe of 2^(2w) and n_occ entries, or -1 when minimizer lines do not pay.  The table must stay within
-// max(64 MiB, 40 bytes per entry, min(9 GiB, 1 KiB per entry)): one MI355X holds 288 GB, and for a set of transcriptome
-// size the 8.6 GB table of w = 15 buys a fifth more point-query throughput than the minimizer records alone, while a tiny
-// set does not get a table thousands of times its own size.  Preferred: the largest g <= 4 with a mean line load of at most
-// 5 of the 16 slots (about 94 % of the entry mass then sits inline and 3 % spills); if that table is too large, the largest
-// g with a load of at most 10 (88 % inline, 9 % spilled).
+// The table must stay within max(64 MiB, 40 bytes per entry, min(9 GiB, 1 KiB per entry)): one MI355X holds 288 GB, and the
+// lines buy a fifth more point-query throughput than the minimizer records alone.  Preferred: a mean line load of at most 5
+// of the 16 slots (about 94 % of the entry mass then sits inline and 3 % spills); if that table is too large, a load of at
+// most 10 (88 % inline, 9 % spilled).
 constexpr uint64_t kFrontFreeBytes = 9ull << 30, kFrontFreeBytesPerEntry = 1024;
-MZ_HD int front_choose_g(uint32_t w, uint64_t n_occ) {
-    if (2 * w > 32) return -1;
+MZ_HD uint64_t front_table_cap(uint64_t n_occ) {
     uint64_t cap = 64ull << 20;
     if (40 * n_occ > cap) cap = 40 * n_occ;
     const uint64_t free_cap = kFrontFreeBytesPerEntry * n_occ < kFrontFreeBytes ? kFrontFreeBytesPerEntry * n_occ : kFrontFreeBytes;
-    if (free_cap > cap) cap = free_cap;
-    for (uint64_t max_load16 = 5; max_load16 <= 10; max_load16 += 5) // mean load allowed, in sixteenths of the line's slots
-        for (int g = (int)(2 * w < kFrontMaxG ? 2 * w : kFrontMaxG); g >= 0; --g) {
-            const uint64_t n_lines = 1ull << (2 * w - g);
-            if (16 * n_occ > max_load16 * kFrontSlots * n_lines) continue;
-            if (n_lines * kFrontSlots * 8 <= cap) return g;
-            break; // smaller g only makes the table larger
-        }
-    return -1;
+    return free_cap > cap ? free_cap : cap;
+}
+MZ_HD bool front_choose_shape(uint32_t w, uint64_t n_occ, uint32_t &g, uint32_t &t) {
+    for (uint64_t max_load = 5; max_load <= 10; max_load += 5)
+        if (front_shape_for_load(w, n_occ, max_load, g, t) && (1ull << (2 * w - g - t)) * kFrontSlots * 8 <= front_table_cap(n_occ)) return true;
+    return false;
 }
 
 // ---- negative filter in the slack of a record's offset block --------------------------------------------

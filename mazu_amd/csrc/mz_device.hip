@@ -312,7 +312,7 @@ __device__ __forceinline__ uint32_t flank_cover_mask(uint32_t off, uint32_t room
     const uint32_t nl = off < kFlankBases ? off : kFlankBases, nr = room < kFlankBases ? room : kFlankBases;
     return ((0xFFu << (2 * (kFlankBases - nl))) & 0xFFu) | (((1u << (2 * nr)) - 1) << 8);
 }
-constexpr uint32_t kFrontIdleKey = 0x1F0u << kFrontKeyShift; // key field no slot can show (real keys use g <= 4 bits, empty slots all nine)
+constexpr uint32_t kFrontIdleKey = 0x100u << kFrontKeyShift; // key field no slot can show (real keys use at most 8 bits, empty slots all nine)
 
 // `lines`: the index has minimizer lines (keys fit 32 bits): the slot pattern of the query and its mask are prepared here,
 // once per query, for stage SF (pattern in the high half of slot[], mask in eoff[], which S3 only needs later)
@@ -355,6 +355,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
         constexpr uint32_t kLpq = kFrontSlots / 2, kQpr = 64 / kLpq; // lanes per query (two slots each), queries per round
         constexpr uint32_t kRounds = 64 * kQpt / kQpr;          // per wavefront
         const uint32_t lane = t & 63, sub = lane % kLpq, grp = lane / kLpq, g = ix.front.g;
+        const uint32_t gl = 2 * w - ix.front.t, line_mask = (uint32_t)(ix.front.n_lines - 1); // word = tag | line index | low g bits: tag starts at bit gl
         const uint32_t wave_q0 = (t >> 6) * (64 * kQpt);      // first item of this wave's share of the tile
         const unsigned long long grp_mask = ((1ull << kLpq) - 1) << (lane & ~(kLpq - 1)), low_mask = grp_mask & ((1ull << lane) - 1); // my query's lanes / those before me
         for (uint32_t r0 = 0; r0 < kRounds; r0 += kFR) { // (a rolling window of requests instead of batches measured the same: the gathers are bandwidth-bound)
@@ -364,8 +365,8 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
             for (int a = 0; a < kFR; ++a) { // all loads of the batch first
                 const uint64_t kp = S.slot[wave_q0 + (r0 + a) * kQpr + grp];     // key | pattern << 32 (an idle slot has key 0: line 0 is always there)
                 const uint32_t key = (uint32_t)kp;
-                pat[a] = (uint32_t)(kp >> 32) | ((key & ((1u << g) - 1)) << kFrontKeyShift);
-                sl[a] = *reinterpret_cast<const ulonglong2 *>(ix.front.lines + (uint64_t)(key >> g) * kFrontSlots + 2 * sub);
+                pat[a] = (uint32_t)(kp >> 32) | (front_keyfield(key, g, gl) << kFrontKeyShift);
+                sl[a] = *reinterpret_cast<const ulonglong2 *>(ix.front.lines + (uint64_t)((key >> g) & line_mask) * kFrontSlots + 2 * sub);
             }
 #pragma unroll
             for (int a = 0; a < kFR; ++a) {

@@ -715,41 +715,49 @@ void SkewTable::build(const uint64_t *words, const uint64_t *pos, uint64_t n, in
     n_ovf = ovf_word.size();
 }
 
-int FrontTable::choose_g(uint32_t w, uint64_t n_occ, bool direct) {
-    if (!direct) return -1; // the lines are addressed by key and built from the minimizer records
+static bool front_forced() { const char *e = std::getenv("MZ_FRONT_TABLE"); return e && e[0] == '1'; }
+
+bool FrontTable::choose(uint32_t w, uint64_t n_occ, bool direct, uint32_t &g, uint32_t &t) {
+    if (!direct || 2 * w > 32) return false; // the lines are addressed by key and built from the minimizer records
     const char *e = std::getenv("MZ_FRONT_TABLE");
-    if (e && e[0] == '0') return -1;
-    if (e && e[0] == '1') { // forced: the largest g that keeps the mean load at or under 10/16 of the slots, whatever the table size
-        if (2 * w > 32) return -1;
-        for (int g = (int)std::min<uint32_t>(2 * w, kFrontMaxG); g >= 0; --g)
-            if (16 * n_occ <= 10 * kFrontSlots * (1ull << (2 * w - g))) return g;
-        return -1;
-    }
-    if (const char *l = std::getenv("MZ_FRONT_MAX_LOAD")) { // experiments: mean line load allowed, in sixteenths of the slots (front_choose_g prefers 5 and accepts 10)
+    if (e && e[0] == '0') return false;
+    if (front_forced()) return front_shape_for_load(w, n_occ, 10, g, t); // whatever the table size
+    if (const char *l = std::getenv("MZ_FRONT_MAX_LOAD")) { // experiments: mean slots per line allowed (front_choose_shape prefers 5 and accepts 10)
         const double load = std::atof(l);
-        if (load > 0 && 2 * w <= 32)
-            for (int g = (int)std::min<uint32_t>(2 * w, kFrontMaxG); g >= 0; --g)
-                if ((double)n_occ * 16.0 <= load * kFrontSlots * (double)(1ull << (2 * w - g))) return g;
+        if (load >= 1) return front_shape_for_load(w, n_occ, (uint64_t)load, g, t);
     }
-    return front_choose_g(w, n_occ);
+    return front_choose_shape(w, n_occ, g, t);
 }
 
-void FrontTable::build(const uint64_t *minrec, uint32_t w, int g_, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads) {
-    present = g_ >= 0;
+bool FrontTable::next_shape(uint32_t w, uint64_t n_occ, uint32_t &g, uint32_t &t) {
+    if (t == 0) return false; // cannot happen: at most 2^g <= 16 keys share a line
+    --t;
+    return front_forced() || (1ull << (2 * w - g - t)) * kFrontSlots * 8 <= front_table_cap(n_occ);
+}
+
+void FrontTable::build(const uint64_t *minrec, uint32_t w, uint64_t n_occ, bool direct, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param,
+                       int n_threads) {
     lines.clear();
-    if (!present) return;
-    g = (uint32_t)g_;
-    const uint64_t n_lines = 1ull << (2 * w - g);
-    lines.resize(n_lines * kFrontSlots);
-    uint64_t *L = lines.data();
-    const uint32_t gg = g;
-    parallel_for(n_threads, n_lines, [=](int, uint64_t b, uint64_t e) {
-        for (uint64_t line = b; line < e; ++line) {
-            uint64_t bucket0;
-            const uint32_t members = front_line_members(minrec, gg, line, bucket0);
-            front_build_line(gg, members, bucket0, psum, entries, skew_param, L + line * kFrontSlots);
-        }
-    });
+    present = choose(w, n_occ, direct, g, t);
+    while (present) {
+        const uint32_t line_bits = 2 * w - g - t;
+        const uint64_t n_lines = 1ull << line_bits;
+        lines.assign(n_lines * kFrontSlots, 0);
+        uint64_t *L = lines.data();
+        const uint32_t gg = g, tt = t;
+        std::vector<uint8_t> bad((size_t)std::max(n_threads, 1), 0);
+        uint8_t *B = bad.data();
+        parallel_for(n_threads, n_lines, [=](int th, uint64_t b, uint64_t e) {
+            for (uint64_t line = b; line < e; ++line)
+                if (!front_build_line(gg, tt, line_bits, line, minrec, psum, entries, skew_param, L + line * kFrontSlots)) B[th] = 1;
+        });
+        bool overfull = false;
+        for (uint8_t x : bad) overfull = overfull || x;
+        if (!overfull) return;
+        present = next_shape(w, n_occ, g, t); // some line has more than 16 member keys: fold the key space less
+    }
+    lines.clear();
+    g = t = 0;
 }
 
 int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads) {
@@ -914,7 +922,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     }
     pos.assign(posv.data(), n_occ, max_pos, nt);
     phase("EF + minrec + pack");
-    front.build(mm.blocks.data(), w, FrontTable::choose_g(w, n_occ, mm.direct != 0), psum.data(), posv.data(), skew_param, nt);
+    front.build(mm.blocks.data(), w, n_occ, mm.direct != 0, psum.data(), posv.data(), skew_param, nt);
     phase("minimizer lines");
     build_seconds = now_s() - t0;
     return MZ_OK;
@@ -951,7 +959,7 @@ uint64_t SSHashHost::num_bits() const { // from the scalars: the arrays may stil
 }
 
 // ------------------------------------------------------------------ flat file
-static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '1', '2'};
+static const char kMagic[8] = {'M', 'Z', 'S', 'S', 'H', '0', '1', '3'};
 template <class T>
 static void put(std::ofstream &f, const T &x) { f.write((const char *)&x, sizeof x); }
 template <class T>
@@ -1000,7 +1008,7 @@ int SSHashHost::save(const std::string &path) const {
     if (has_skew) { put(f, skew.n_buckets); put(f, skew.n_keys); put(f, skew.fp_bits); putv(f, skew.buckets); putv(f, skew.ovf_word); putv(f, skew.ovf_pos); }
     const uint32_t hf = front.present ? 1 : 0;
     put(f, hf);
-    if (front.present) { put(f, front.g); putv(f, front.lines); }
+    if (front.present) { put(f, front.g); put(f, front.t); putv(f, front.lines); }
     return f ? MZ_OK : (set_error("short write to %s", path.c_str()), MZ_EIO);
 }
 
@@ -1061,7 +1069,7 @@ static const char *check_loaded(const SSHashHost &h) {
     }
     if (h.front.present) { // every slot must point inside the entry array / the sequence
         const FrontTable &t = h.front;
-        if (!h.mm.direct || t.g > kFrontMaxG || t.g > 2 * h.w || t.lines.size() != (1ull << (2 * h.w - t.g)) * kFrontSlots) return "minimizer lines";
+        if (!h.mm.direct || t.g > kFrontMaxG || t.g + t.t > kFrontMaxKeyBits || t.g + t.t > 2 * h.w || t.lines.size() != (1ull << (2 * h.w - t.g - t.t)) * kFrontSlots) return "minimizer lines";
         for (uint64_t e : t.lines) {
             const uint32_t kind = (uint32_t)e & 3u;
             const uint64_t a = e >> kFrontPosShift;
@@ -1090,7 +1098,7 @@ int SSHashHost::load(const std::string &path) {
     ok = ok && get(f, hf);
     front.present = hf != 0;
     front.lines.clear();
-    if (ok && front.present) ok = get(f, front.g) && getv(f, front.lines);
+    if (ok && front.present) ok = get(f, front.g) && get(f, front.t) && getv(f, front.lines);
     if (!ok) {
         set_error("%s: truncated", path.c_str());
         return MZ_EIO;

@@ -108,13 +108,16 @@ struct SkewTable {
 // entry array; the GPU builder produces the same words.
 struct FrontTable {
     std::vector<uint64_t> lines;
-    uint32_t g = 0;
+    uint32_t g = 0, t = 0;
     bool present = false;
-    // MZ_FRONT_TABLE=0 never builds the lines, =1 builds them whenever a g exists (ignoring the size rule), otherwise front_choose_g decides
-    static int choose_g(uint32_t w, uint64_t n_occ, bool direct);
-    void build(const uint64_t *minrec, uint32_t w, int g_, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads);
-    FrontView view() const { return present ? FrontView{lines.data(), (uint64_t)lines.size() / kFrontSlots, g, 0} : FrontView{nullptr, 0, 0, 0}; }
-    uint64_t n_words(uint32_t w) const { return present ? (1ull << (2 * w - g)) * kFrontSlots : 0; }
+    // shape of the table for this index, false when none is built.  MZ_FRONT_TABLE=0 never builds the lines, =1 builds them
+    // at a load of at most 10 whatever the table size, otherwise front_choose_shape decides; MZ_FRONT_MAX_LOAD sets the load
+    static bool choose(uint32_t w, uint64_t n_occ, bool direct, uint32_t &g, uint32_t &t);
+    // after a table turned out to have a line with more than 16 member keys: the next shape to try (half the tag), false when there is none
+    static bool next_shape(uint32_t w, uint64_t n_occ, uint32_t &g, uint32_t &t);
+    void build(const uint64_t *minrec, uint32_t w, uint64_t n_occ, bool direct, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads);
+    FrontView view() const { return present ? FrontView{lines.data(), (uint64_t)lines.size() / kFrontSlots, g, t} : FrontView{nullptr, 0, 0, 0}; }
+    uint64_t n_words(uint32_t w) const { return present ? (1ull << (2 * w - g - t)) * kFrontSlots : 0; }
 };
 
 struct SSHashHost {

@@ -161,7 +161,7 @@ class FlatIndexFile:
 
     def __init__(self, data):
         self.d = bytearray(data)
-        assert bytes(self.d[:8]) == b"MZSSH012"
+        assert bytes(self.d[:8]) == b"MZSSH013"
         o = 8
         self.k, self.w = struct.unpack_from("<II", self.d, o); o += 8
         self.seed, self.skew_param, self.total_len, self.n_unitigs, self.n_minimizers = struct.unpack_from("<5Q", self.d, o); o += 40
@@ -186,7 +186,7 @@ class FlatIndexFile:
             o = vec("skew_buckets", o); o = vec("skew_ovf_word", o); o = vec("skew_ovf_pos", o)
         (self.has_front,) = struct.unpack_from("<I", self.d, o); o += 4
         if self.has_front:
-            (self.front_g,) = struct.unpack_from("<I", self.d, o); o += 4
+            (self.front_g, self.front_t) = struct.unpack_from("<II", self.d, o); o += 8
             o = vec("front_lines", o)
         assert o == len(self.d), (o, len(self.d))
 

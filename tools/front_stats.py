@@ -21,7 +21,7 @@ def vec_offsets(path):
     """(offset, count) of every length-prefixed vector of the flat index file, in file order"""
     out = {}
     with open(path, "rb") as fh:
-        assert fh.read(8) == b"MZSSH012"
+        assert fh.read(8) == b"MZSSH013"
         fh.seek(8 + 8 + 40)
         (has_skew,) = struct.unpack("<I", fh.read(4))
 
