@@ -54,3 +54,36 @@ def test_random_configurations_match_the_dictionary(block):
                 assert got.tobytes() == truth.tobytes(), what
             else:  # duplicate k-mers (outside the parity contract): which occurrence answers is not fixed, hit / miss is
                 assert np.array_equal(got["match"] != 0, truth["match"] != 0), what
+
+
+def test_folded_lines_retry_when_a_line_overflows(monkeypatch, tmp_path):
+    """A minimizer-line table folded so hard that some line would hold more than 16 member keys is rebuilt with less folding,
+    identically by the host and the GPU builder (the flat files are compared byte for byte), and answers like the dictionary."""
+    monkeypatch.setenv("MZ_FRONT_MAX_LOAD", "1000")  # start from the fewest lines the slot's key field allows
+    rng = np.random.default_rng(77)
+    for c, (k, w) in enumerate([(31, 11), (25, 9), (31, 12)]):
+        seed = int(rng.integers(0, 1 << 30))
+        codes, starts = H.random_unitigs(seed, 2500, 300.0, k, max_len=3000)
+        total = int(starts[-1])
+        words = H.pack_codes(codes)
+        orc = O.OracleSSHash(words, total, starts, k, w, 32, seed)
+        us = M.UnitigSet.from_packed(words, total, starts, k)
+        q = H.query_mix(words, starts, k, 40000, seed=seed & 0xFFFF)
+        truth, _ = orc.k2u_batch(q, n_threads=8, use_dict=True)
+        files = []
+        for how in ("host", "gpu"):
+            ix = M.SSHash.from_unitig_set(us, w, 32, seed) if how == "host" else M.SSHash.from_unitig_set_on_device(us, w, 32, seed)
+            assert ix.has_minimizer_lines(), (c, how)
+            got, _ = ix.k2u_batch(q)
+            rep = ix.validate_self_report()
+            assert rep["n_fail"] == 0 and rep["n_kmers"] == ix.n_kmers(), (c, how)
+            if orc.n_duplicate_kmers() == 0:
+                assert got.tobytes() == truth.tobytes(), (c, how)
+            path = tmp_path / f"{c}_{how}.mz"
+            ix.save(path)
+            files.append(open(path, "rb").read())
+        assert files[0] == files[1], c
+        if c == 1:  # 4^9 words over 1024 lines at full folding: the builders had to back off
+            from test_gpu_configs import FlatIndexFile
+            f = FlatIndexFile(files[0])
+            assert f.has_front and f.front_g + f.front_t < 8 and f.n("front_lines") == 16 * 4 ** w >> (f.front_g + f.front_t)
