@@ -140,11 +140,12 @@ uint64_t mz_sshash_n_minimizer_occs(const mz_sshash *ix);
 uint64_t mz_sshash_n_kmers_in_skew_index(const mz_sshash *ix);
 uint64_t mz_sshash_num_bits(const mz_sshash *ix);
 /* form of the minimizer MPHF (the reference's boomphf, sshash.rs:177): 1 = direct-address minimizer records (2w <= 32 and
- * the record table small next to the key set), 0 = BBHash levels */
+ * the record table within max(64 MiB, 48 bytes per key, min(1 GiB, 1 KiB per key))), 0 = BBHash levels */
 uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix);
 /* 1 when the index carries minimizer lines: membership and the entries of most buckets (sshash.rs:478-495: MPHF probe, two
  * Elias-Fano offsets, position array) answered by one 128-byte gather.  Built for direct-address minimizers when the table
- * stays within max(64 MiB, 40 bytes per entry); MZ_FRONT_TABLE=0 / 1 in the environment of the BUILD disables / forces it. */
+ * (sized by the entries: at most 5, else at most 10 per line of 16 slots) stays within max(64 MiB, 40 bytes per entry,
+ * min(9 GiB, 1 KiB per entry)); MZ_FRONT_TABLE=0 / 1 in the environment of the BUILD disables / forces it. */
 uint32_t mz_sshash_has_minimizer_lines(const mz_sshash *ix);
 /* bytes resident in HBM once uploaded */
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix);
