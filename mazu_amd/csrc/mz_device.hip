@@ -113,7 +113,8 @@ constexpr int kStopAfter = MZ_STOP_AFTER;
 #endif
 constexpr int kRecBatch = MZ_REC_BATCH; // minimizer records in flight per lane (S1)
 // S.n[i]: bucket size (< kNSkew), or one of the markers below (kNIdle: no query in this slot)
-constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu, kNPending = 0xFFFFFFFCu; // kNPending: SF left a marker slot in slot[i]
+constexpr uint32_t kNMiss = 0xFFFFFFFFu, kNIdle = 0xFFFFFFFEu, kNSkew = 0xFFFFFFFDu, kNPending = 0xFFFFFFFCu, kNExact = 0xFFFFFFFBu; // kNPending: SF left a marker slot in slot[i]; kNExact (runs only): the bucket's size is unknown, exact walk
+constexpr uint64_t kSlotInLine = 1ull << 63; // slot[i] (bucket start) points into the minimizer lines (slot layout) instead of the entry array
 // S.qinfo[i]: the flank16 an entry must show for item i (mz_common.hpp `pos` entry), in the orientation of the canonical
 // word g*: bits 0..7 = the 4 bases left of the minimizer in g*, bits 8..15 = the 4 bases right of it | offset << 16 |
 // kQMulti once a second bucket entry survived the flank filter
@@ -347,7 +348,8 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     //          dense pass afterwards (one lane per query, all lanes busy) turns parked slots into the candidate position for
     //          S5, a skew-index request for S4, or -- for a bucket that did not fit its line -- its range in the entry array
     //          for S3.  A query none of whose line's slots carries its key is a miss.
-    if (ix.front.lines != nullptr) {
+    constexpr bool kRunScope = kRuns && SC::NT == 64;
+    if (ix.front.lines != nullptr && !kRunScope) {
 #ifndef MZ_SF_BATCH
 #define MZ_SF_BATCH 8
 #endif
@@ -421,7 +423,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     } else
     // ---- S1: minimizer -> bucket id.  Direct-address rank bitmap (2w <= 32): one dense gather, no rounds;
     //          otherwise the BBHash level loop
-    if (kRuns && SC::NT == 64) {
+    if (kRunScope) {
         // S1+S2 once per run of equal keys.  Items are numbered along the read (item q * 64 + lane).  The windows whose canonical
         // k-mer is the forward strand keep their minimizer for a stretch of positions, and so do those whose canonical k-mer is
         // the reverse strand, but the two strands interleave at random: an item belongs to the run of the nearest earlier item of
@@ -464,7 +466,53 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
             n_runs += (uint32_t)__popcll(lead_b);
         }
         SC::sync();
-        if (ix.mm.direct) {
+        if (ix.front.lines != nullptr) {
+            // leaders through the minimizer lines: eight lanes fetch the leader's line (one coalesced 16-byte load each) and find
+            // the slots of its key -- they are contiguous, in bucket order.  The run's "bucket" is then that stretch of the line
+            // itself (slot[] flagged kSlotInLine: S3 reads and decodes slots instead of entries), or what the key's marker says.
+            constexpr uint32_t kLpq = kFrontSlots / 2, kQpr = 64 / kLpq;
+            const uint32_t sub = lane % kLpq, grp = lane / kLpq, g = ix.front.g, gl = 2 * w - ix.front.t, line_mask = (uint32_t)(ix.front.n_lines - 1);
+            const unsigned long long grp_mask = ((1ull << kLpq) - 1) << (lane & ~(kLpq - 1));
+            for (uint32_t base = 0; base < n_runs; base += kQpr * 4) {
+                ulonglong2 sl[4];
+                uint32_t pat[4], item[4];
+                uint64_t line0[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { // the loads of four rounds first
+                    const uint32_t li = base + a * kQpr + grp;
+                    item[a] = li < n_runs ? S.eoff[li] : ~0u;
+                    const uint32_t key = item[a] != ~0u ? (uint32_t)S.slot[item[a]] : 0u; // (no leader: line 0 is always there)
+                    pat[a] = front_keyfield(key, g, gl) << kFrontKeyShift;
+                    line0[a] = (uint64_t)((key >> g) & line_mask) * kFrontSlots;
+                    sl[a] = *reinterpret_cast<const ulonglong2 *>(ix.front.lines + line0[a] + 2 * sub);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const uint32_t x0 = (uint32_t)sl[a].x ^ pat[a], x1 = (uint32_t)sl[a].y ^ pat[a];
+                    const bool e0 = (x0 & (kFrontKeyMask | 3u)) == 0, e1 = (x1 & (kFrontKeyMask | 3u)) == 0;      // entries of the key
+                    const bool m0 = (x0 & (kFrontKeyMask | 3u)) - 1u < 2u, m1 = (x1 & (kFrontKeyMask | 3u)) - 1u < 2u; // its heavy / spill marker
+                    const unsigned long long b0 = __ballot(e0) & grp_mask, b1 = __ballot(e1) & grp_mask, mb = __ballot(m0 || m1) & grp_mask;
+                    const uint32_t i = item[a];
+                    if (i == ~0u) continue;
+                    if (m0 || m1) {
+                        const uint64_t e = m0 ? sl[a].x : sl[a].y;
+                        const uint32_t cnt = (uint32_t)(e >> kFrontFlankShift) & 0xFFFFu;
+                        S.slot[i] = e >> kFrontPosShift;
+                        S.n[i] = ((uint32_t)e & 3u) == kFrontHeavy ? kNSkew : cnt == 0xFFFFu ? kNExact : cnt; // 0xFFFF: size not in the marker (no skew index)
+                    } else if (sub == 0 && mb == 0) {
+                        const unsigned long long any = b0 | b1;
+                        if (any == 0) {
+                            S.n[i] = kNMiss; // no slot of this key in its line: not a minimizer of the set
+                        } else {
+                            const uint32_t fl = (uint32_t)__ffsll((long long)any) - 1;                    // first lane (of the wave) holding one
+                            const uint32_t f = 2 * (fl % kLpq) + (((b0 >> fl) & 1) ? 0u : 1u);          // first slot of the key
+                            S.slot[i] = kSlotInLine | (line0[a] + f);
+                            S.n[i] = (uint32_t)(__popcll(b0) + __popcll(b1));
+                        }
+                    }
+                }
+            }
+        } else if (ix.mm.direct) {
             for (uint32_t base = 0; base < n_runs; base += 64) {
                 const bool have = base + lane < n_runs;
                 const uint32_t i = have ? S.eoff[base + lane] : 0u;
@@ -515,6 +563,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
         for (int q = 0; q < kQpt; ++q) {
             const uint32_t i = q * 64 + lane;
             if ((follows >> q) & 1u) { S.slot[i] = cps[q]; S.n[i] = cn[q]; }
+            if (cn[q] == kNExact) { S.best[i] = 0; S.qinfo[i] |= kQMulti; S.n[i] = 0; } // position 0 fails its verification (or is the answer): exact walk
             wave_push(S.list_b, &S.cnt_skew, cn[q] == kNSkew, i);
         }
     } else if (ix.mm.direct) {
@@ -678,6 +727,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
             SC::sync();
             uint32_t jdx[kEpt];
             uint64_t ent[kEpt];
+            bool canon[kEpt] = {}; // the entry's flanks are already in the orientation of the canonical k-mer (it came from a minimizer line)
 #pragma unroll
             for (int a = 0; a < kEpt; ++a) own[a] = S.list_a[a * SC::NT + t];
             SC::sync(); // the mark array is rewritten by the next chunk
@@ -687,7 +737,16 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 const uint32_t ec = e < E ? e : E - 1;
                 if (e >= E) own[a] = carry;
                 jdx[a] = ec - S.eoff[own[a]];
-                ent[a] = ix.pos[S.slot[own[a]] + jdx[a]];                                           // sshash.rs:495
+                const uint64_t sb = S.slot[own[a]];
+                if constexpr (kRunScope) { // a run resolved through the minimizer lines reads its entries from the line itself
+                    const uint64_t *src = (sb & kSlotInLine) ? ix.front.lines : ix.pos;
+                    const uint64_t e = src[(sb & ~kSlotInLine) + jdx[a]];
+                    // slot -> entry layout (the slot's flanks are already in the orientation of the canonical k-mer: bit 63 of jdx marks that)
+                    ent[a] = (sb & kSlotInLine) ? make_entry(e >> kFrontPosShift, (uint32_t)(e >> kFrontClsShift) & 1u, (uint32_t)(e >> kFrontFlankShift) & 0xFFFFu) : e;
+                    canon[a] = (sb & kSlotInLine) != 0;
+                } else {
+                    ent[a] = ix.pos[sb + jdx[a]];                                                   // sshash.rs:495
+                }
             }
 #pragma unroll
             for (int a = 0; a < kEpt; ++a) {
@@ -702,7 +761,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 const uint32_t nl = off_a < kFlankBases ? off_a : kFlankBases, nr = room < kFlankBases ? room : kFlankBases;
                 const uint32_t mask = ((0xFFu << (2 * (kFlankBases - nl))) & 0xFFu) | (((1u << (2 * nr)) - 1) << 8);
                 const uint32_t fl = (uint32_t)(ent[a] & 0xFFFFu);
-                if ((((cls ? flank_revcomp(fl) : fl) ^ qi) & mask) != 0 || mm_pos < off || mm_pos - off > last_km_start) continue;
+                if ((((cls && !canon[a] ? flank_revcomp(fl) : fl) ^ qi) & mask) != 0 || mm_pos < off || mm_pos - off > last_km_start) continue;
                 // the first survivor in bucket order is the item's candidate (verified in S5); a second one is only flagged
                 const uint64_t jj = jdx[a] < 0x3FFFFFFu ? jdx[a] : 0x3FFFFFFu;
                 const unsigned long long old = atomicMin(&S.best[i], (jj << (kPosBits + 1)) | (mm_pos - off));
@@ -1228,7 +1287,7 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
                     mn = window_minimizer(R, i, fw, rc, k, w);
                 }
             }
-            tile_set_query<SC>(S, it, fw, rc, mn, k, w, query, ix.front.lines != nullptr);
+            tile_set_query<SC>(S, it, fw, rc, mn, k, w, query, false); // (runs are resolved per leader: no per-item line pattern)
             if (state[q] == 1) { // non-ACGT window: reported, never queried
                 mz_k2upos sk = make_none();
                 sk.match = MZ_SKIPPED;
