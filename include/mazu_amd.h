@@ -144,7 +144,7 @@ uint64_t mz_sshash_num_bits(const mz_sshash *ix);
 uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix);
 /* 1 when the index carries minimizer lines: membership and the entries of most buckets (sshash.rs:478-495: MPHF probe, two
  * Elias-Fano offsets, position array) answered by one 128-byte gather.  Built for direct-address minimizers when the table
- * (sized by the entries: at most 5, else at most 10 per line of 16 slots) stays within max(64 MiB, 40 bytes per entry,
+ * (sized by the entries: at most 3, else 5, else 10 per line of 16 slots) stays within max(64 MiB, 64 bytes per entry,
  * min(9 GiB, 1 KiB per entry)); MZ_FRONT_TABLE=0 / 1 in the environment of the BUILD disables / forces it. */
 uint32_t mz_sshash_has_minimizer_lines(const mz_sshash *ix);
 /* bytes resident in HBM once uploaded */

@@ -562,20 +562,22 @@ MZ_HD bool front_shape_for_load(uint32_t w, uint64_t n_occ, uint64_t max_load, u
     t = u - line_bits - g;
     return true;
 }
-// The table must stay within max(64 MiB, 40 bytes per entry, min(9 GiB, 1 KiB per entry)): one MI355X holds 288 GB, and the
-// lines buy a fifth more point-query throughput than the minimizer records alone.  Preferred: a mean line load of at most 5
-// of the 16 slots (about 94 % of the entry mass then sits inline and 3 % spills); if that table is too large, a load of at
-// most 10 (88 % inline, 9 % spilled).
-constexpr uint64_t kFrontFreeBytes = 9ull << 30, kFrontFreeBytesPerEntry = 1024;
+// The table must stay within max(64 MiB, 64 bytes per entry, min(9 GiB, 1 KiB per entry)): one MI355X holds 288 GB, and the
+// lines buy a fifth more point-query throughput than the minimizer records alone.  Preferred: a mean line load of at most 3
+// of the 16 slots (S-human: 2.0 entries per line, 96 % of the entry mass inline, 1.3 % spilled -- a spilled bucket costs a
+// query an extra dependent access, and 6 % of the throughput separate this shape from the next); if that table is too
+// large, a load of at most 5 (94 % inline, 3 % spilled), then at most 10 (88 % inline, 9 % spilled).
+constexpr uint64_t kFrontFreeBytes = 9ull << 30, kFrontFreeBytesPerEntry = 1024, kFrontBytesPerEntry = 64;
 MZ_HD uint64_t front_table_cap(uint64_t n_occ) {
     uint64_t cap = 64ull << 20;
-    if (40 * n_occ > cap) cap = 40 * n_occ;
+    if (kFrontBytesPerEntry * n_occ > cap) cap = kFrontBytesPerEntry * n_occ;
     const uint64_t free_cap = kFrontFreeBytesPerEntry * n_occ < kFrontFreeBytes ? kFrontFreeBytesPerEntry * n_occ : kFrontFreeBytes;
     return free_cap > cap ? free_cap : cap;
 }
 MZ_HD bool front_choose_shape(uint32_t w, uint64_t n_occ, uint32_t &g, uint32_t &t) {
-    for (uint64_t max_load = 5; max_load <= 10; max_load += 5)
-        if (front_shape_for_load(w, n_occ, max_load, g, t) && (1ull << (2 * w - g - t)) * kFrontSlots * 8 <= front_table_cap(n_occ)) return true;
+    const uint64_t loads[3] = {3, 5, 10};
+    for (int a = 0; a < 3; ++a)
+        if (front_shape_for_load(w, n_occ, loads[a], g, t) && (1ull << (2 * w - g - t)) * kFrontSlots * 8 <= front_table_cap(n_occ)) return true;
     return false;
 }
 

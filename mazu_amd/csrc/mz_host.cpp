@@ -722,7 +722,7 @@ bool FrontTable::choose(uint32_t w, uint64_t n_occ, bool direct, uint32_t &g, ui
     const char *e = std::getenv("MZ_FRONT_TABLE");
     if (e && e[0] == '0') return false;
     if (front_forced()) return front_shape_for_load(w, n_occ, 10, g, t); // whatever the table size
-    if (const char *l = std::getenv("MZ_FRONT_MAX_LOAD")) { // experiments: mean slots per line allowed (front_choose_shape prefers 5 and accepts 10)
+    if (const char *l = std::getenv("MZ_FRONT_MAX_LOAD")) { // experiments: mean slots per line allowed (front_choose_shape prefers 3 and accepts 5 or 10)
         const double load = std::atof(l);
         if (load >= 1) return front_shape_for_load(w, n_occ, (uint64_t)load, g, t);
     }
