@@ -1109,14 +1109,16 @@ __device__ __forceinline__ void window_minima_17(const uint32_t *keys, uint32_t 
     out[3] = min(min3u(x[17], x[18], x[19]), mid);
 }
 
-// Every window is an independent lookup through the tile machinery (the loop of bin/kphf/main.rs:314-324).
+// Every window is looked up through the tile machinery (the loop of bin/kphf/main.rs:314-324); what consecutive windows
+// share -- their minimizer, for ~9 positions -- is resolved once per run (tile_resolve<SC, true>).
 // The `.as_streaming()` shortcut of the reference (index/caching.rs:65-103: try prev.pos+1 on the same
-// unitig first) was also built here as "look up one anchor window per 32, extend the rest along the
+// unitig first) was also built here, twice, as "look up one anchor window per 32, extend the rest along the
 // anchor's unitig in both directions, fall back to the lookup": it returned identical results but ran
 // SLOWER than looking every window up (11.0 vs 12.3 G k-mers/s on clean reads over long unitigs, 6.2 vs
-// 8.9 on the junction-heavy s-txome set): with one 128-byte line per negative and ~3 per positive the
-// lookup is cheaper than a second staged pass.  Streaming requests therefore take this same path; by
-// the reference's own contract (and for every unique-k-mer set) the results are the same.
+// 8.9 on the junction-heavy s-txome set at the time): every window's k-mer has to be compared with the sequence
+// either way, and a window that fails the extension (an error, a junction: a third of the windows of the
+// benchmark's reads) needs the full lookup in a second staged pass.  Streaming requests therefore take this
+// same path; by the reference's own contract (and for every unique-k-mer set) the results are the same.
 template <uint32_t KW>
 __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
                                                            const uint64_t *__restrict__ read_offsets,
