@@ -87,3 +87,52 @@ def test_folded_lines_retry_when_a_line_overflows(monkeypatch, tmp_path):
             from test_gpu_configs import FlatIndexFile
             f = FlatIndexFile(files[0])
             assert f.has_front and f.front_g + f.front_t < 8 and f.n("front_lines") == 16 * 4 ** w >> (f.front_g + f.front_t)
+
+
+@pytest.mark.parametrize("reads_lines", ["1", "0"])
+def test_bucket_larger_than_a_marker_can_say_without_a_skew_index(monkeypatch, reads_lines):
+    """90 000 unitigs that all carry one 21-base motif between unique flanks: without a skew index their shared minimizer owns a
+    bucket whose size does not fit the 16-bit count of a minimizer-line spill marker, so lookups through the lines (point queries,
+    and reads resolved per run of windows) must fall back to the exact in-order walk of sshash.rs:494-553."""
+    monkeypatch.setenv("MZ_READS_LINES", reads_lines)
+    rng = np.random.default_rng(5)
+    k, w, n = 31, 11, 90000
+    motif = rng.integers(0, 4, 21, dtype=np.uint8)
+    idx = np.arange(n, dtype=np.int64)
+    flank = np.stack([(idx >> (2 * j)) & 3 for j in range(10)], axis=1).astype(np.uint8)  # unitig number in base 4: unique 31-mers
+    codes = np.concatenate([flank[:, :5], np.broadcast_to(motif, (n, 21)), flank[:, 5:]], axis=1).reshape(-1)
+    # plus ordinary random unitigs, so that the set has light buckets as well
+    extra, extra_starts = H.random_unitigs(9, 400, 200.0, k, max_len=2000)
+    starts = np.concatenate([np.arange(n, dtype=np.uint64) * 31, np.uint64(n * 31) + extra_starts])
+    codes = np.concatenate([codes, extra])
+    total = int(starts[-1])
+    words = H.pack_codes(codes)
+    orc = O.OracleSSHash(words, total, starts, k, w, M.MZ_NO_SKEW_INDEX, 0)
+    us = M.UnitigSet.from_packed(words, total, starts, k)
+    ix = M.SSHash.from_unitig_set_no_skew_index(us, w)
+    assert ix.has_minimizer_lines() and ix.minimizer_mphf_kind() == 1
+    q = H.query_mix(words, starts, k, 60000, seed=3)
+    truth, _ = orc.k2u_batch(q, n_threads=8, use_dict=True)
+    got, _ = ix.k2u_batch(q)
+    rep = ix.validate_self_report()
+    assert rep["n_fail"] == 0 and rep["n_kmers"] == ix.n_kmers()
+    if orc.n_duplicate_kmers() == 0:
+        assert got.tobytes() == truth.tobytes()
+    else:
+        assert np.array_equal(got["match"] != 0, truth["match"] != 0)
+    # reads: the first 3 000 motif unitigs as 31-base reads (one window each) and 300 reads cut from the random unitigs
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [letters[codes[31 * i:31 * i + 31]] for i in range(3000)]
+    for j in range(300):
+        a = int(starts[n + j]); b = int(starts[n + j + 1])
+        reads.append(letters[codes[a:min(b, a + 150)]])
+    ro = np.zeros(len(reads) + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in reads], out=ro[1:].view(np.int64))
+    bases = np.concatenate(reads)
+    want, _, oc = orc.k2u_reads(bases, ro, streaming=True)
+    got_r, cnt = ix.k2u_reads(bases, ro, streaming=True)
+    if orc.n_duplicate_kmers() == 0:
+        assert got_r.tobytes() == want.tobytes() and list(cnt) == oc.tolist()
+    else:
+        assert np.array_equal(got_r["match"] != 0, want["match"] != 0)
+    assert cnt[0] >= 3000
