@@ -1311,6 +1311,195 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
 }
 
 // ------------------------------------------------------------------------------------
+// K: reads, wave-scoped (the (31, 15) configuration).  Same stages as k2u_reads_kernel, but every wavefront stages its
+// OWN 256 positions (+ the 30-base tail its last windows need) in its own LDS slice and walks front end and lookups
+// alone: no workgroup barrier anywhere, so a wave never waits for the slowest of four, and the read bookkeeping that one
+// wave did for the whole workgroup is done by each wave for its tile.  The tail is staged twice (by this wave and as the
+// head of the next tile): 18 % more front-end work for no synchronisation.
+// ------------------------------------------------------------------------------------
+constexpr int kWaveTile = 64 * kQpt;   // positions per wave tile
+constexpr int kWaveReadsStaged = 32;   // reads whose offsets are staged per wave tile
+struct alignas(16) ReadsWaveLds {
+    uint64_t plane_lo[kQpt + 2], plane_hi[kQpt + 2], plane_inv[kQpt + 2]; // kQpt rows of 64 positions, the tail row, a pad word
+    uint64_t packed[kWaveTile / 32 + 4];                                    // 2-bit packed bases of the tile and its tail
+    uint32_t keys_f[kWaveTile + 32], keys_r[kWaveTile + 32];                // window keys (see window_minima_17), then the window minima
+    uint64_t roff[kWaveReadsStaged + 1], koff[kWaveReadsStaged + 1];
+    uint64_t start_plane[kQpt];
+    uint32_t start_cum[kQpt];
+    uint64_t read0;
+    uint32_t slow;
+};
+__device__ __forceinline__ uint64_t packed_mer(const uint64_t *packed, uint32_t i, uint32_t len) {
+    const uint32_t wi = i >> 5, sh = 2 * (i & 31);
+    const uint64_t lo = packed[wi], hi = packed[wi + 1];
+    return ((lo >> sh) | ((hi << 1) << (63 - sh))) & kmer_mask(len);
+}
+__global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
+                                                                              const uint64_t *__restrict__ read_offsets,
+                                                                              const uint64_t *__restrict__ kmer_offsets, uint64_t n_reads,
+                                                                              mz_k2upos *__restrict__ out, mz_counts *counts) {
+    fix_kw<kKW3115>(ix);
+    using SC = WaveScope;
+    __shared__ TileLdsT<SC::NT> SS[kBlock / 64];
+    __shared__ ReadsWaveLds RR[kBlock / 64];
+    constexpr uint32_t k = 31, w = 15, n_win = k - w + 1, T = kWaveTile;
+    static_assert(T + n_win - 1 <= kWaveTile + 32 - 12 && 4 * 63 + 19 < kWaveTile + 32, "keys of the tile and its 16-position tail");
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    TileLdsT<SC::NT> &S = SS[wave];
+    ReadsWaveLds &R = RR[wave];
+    const uint64_t n_tiles = (n_bases + T - 1) / T, n_waves = (uint64_t)gridDim.x * (kBlock / 64), wave_id = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
+    // every wave takes a contiguous run of tiles, so the read that holds a tile's first base follows from the previous tile
+    const uint64_t tiles_per_wave = (n_tiles + n_waves - 1) / n_waves;
+    const uint64_t tile_first = wave_id * tiles_per_wave, tile_end = tile_first + tiles_per_wave < n_tiles ? tile_first + tiles_per_wave : n_tiles;
+    uint64_t next_read0 = ~0ull; // read0 of the next tile when it is known, else ~0 (search)
+    Tally tally;
+    for (uint64_t tile = tile_first; tile < tile_end; ++tile) {
+        const uint64_t B0 = tile * T;
+        tile_begin<SC>(S);
+        uint32_t code[kQpt];
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) { // the loads first: the reads are looked up while they are in flight
+            const uint64_t b = B0 + (uint64_t)q * 64 + lane;
+            code[q] = b < n_bases ? bases[b] : (uint32_t)'N';
+        }
+        const uint64_t bt = B0 + T + lane;
+        const uint32_t tail_code = (lane < k - 1 && bt < n_bases) ? bases[bt] : (uint32_t)'N';
+        {
+            // read holding the first base of the tile: largest r with read_offsets[r] <= B0.  Carried over from the previous tile,
+            // else a 64-ary search (every lane probes one offset per round)
+            uint64_t r0 = next_read0;
+            if (r0 == ~0ull) {
+                uint64_t lo = 0, hi = n_reads; // invariant: read_offsets[lo] <= B0 < read_offsets[hi] (offsets[n_reads] = n_bases > B0)
+                while (hi - lo > 1) {
+                    const uint64_t step = (hi - lo + 63) >> 6, idx = lo + (uint64_t)lane * step;
+                    const bool le = idx < hi && read_offsets[idx] <= B0;
+                    const uint32_t c = (uint32_t)__popcll(__ballot(le)); // probes are ascending: the first c of them are <= B0 (c >= 1: lane 0 probes lo)
+                    lo = lo + (uint64_t)(c - 1) * step;
+                    hi = lo + step < hi ? lo + step : hi;
+                }
+                r0 = lo;
+            }
+            // offsets of the reads r0 .. r0 + 32 (beyond the last read: +infinity) and their first output slots, one per lane
+            const bool in = lane < kWaveReadsStaged;
+            const uint64_t j0 = r0 + lane, j1 = r0 + kWaveReadsStaged;
+            const uint64_t o0 = in && j0 <= n_reads ? read_offsets[j0] : ~0ull, o1 = j1 <= n_reads ? read_offsets[j1] : ~0ull;
+            const uint64_t k0 = in && j0 < n_reads ? kmer_offsets[j0] : 0ull;
+            if (in) { R.roff[lane] = o0; R.koff[lane] = k0; }
+            if (lane == 0) { R.roff[kWaveReadsStaged] = o1; R.koff[kWaveReadsStaged] = 0; R.read0 = r0; }
+            if (lane < kQpt) R.start_plane[lane] = 0;
+            const uint64_t o_next = (uint64_t)__shfl((unsigned long long)o0, (int)((lane + 1) & 63)); // offset of read r0 + lane + 1
+            const uint64_t nxt = lane == kWaveReadsStaged - 1 ? o1 : o_next;
+            // slow walk when a 33rd read could start inside the tile (+ its k-1 tail) or a staged read that matters is empty
+            const bool empty_read = in && o0 != ~0ull && nxt == o0 && o0 < B0 + T + k;
+            const bool too_many = o1 != ~0ull && o1 < B0 + T + k;
+            const bool slow = __ballot(empty_read) != 0 || too_many;
+            if (lane == 0) R.slow = slow ? 1u : 0u;
+            SC::sync(); // start_plane is cleared before bits are set
+            const bool starts_here = in && lane >= 1 && o0 > B0 && o0 < B0 + T; // read r0 + lane starts at tile position o0 - B0 (> 0)
+            if (starts_here) atomicOr((unsigned long long *)&R.start_plane[(o0 - B0) >> 6], 1ull << ((o0 - B0) & 63));
+            // next tile: reads that start at or before its first base
+            const uint32_t adv = (uint32_t)__popcll(__ballot(in && lane >= 1 && o0 <= B0 + T));
+            next_read0 = slow || adv == kWaveReadsStaged - 1 ? ~0ull : r0 + adv;
+            SC::sync();
+            const uint32_t c = lane < kQpt ? (uint32_t)__popcll(R.start_plane[lane]) : 0u; // exclusive prefix counts of the start plane
+            const uint32_t cum = wave_scan<false>(c) - c;
+            if (lane < kQpt) R.start_cum[lane] = cum;
+        }
+        // bit planes: one ballot triple per row of 64 positions, the tail row, a pad word
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            const uint32_t c = base_code_dev((uint8_t)code[q]);
+            const unsigned long long blo = __ballot(c & 1u), bhi = __ballot((c >> 1) & 1u), binv = __ballot(c >> 2);
+            if (lane == 0) { R.plane_lo[q] = blo; R.plane_hi[q] = bhi; R.plane_inv[q] = binv; }
+        }
+        {
+            const uint32_t c = base_code_dev((uint8_t)tail_code);
+            const unsigned long long blo = __ballot(c & 1u), bhi = __ballot((c >> 1) & 1u), binv = __ballot(c >> 2);
+            if (lane == 0) {
+                R.plane_lo[kQpt] = blo; R.plane_hi[kQpt] = bhi; R.plane_inv[kQpt] = binv;
+                R.plane_lo[kQpt + 1] = 0; R.plane_hi[kQpt + 1] = 0; R.plane_inv[kQpt + 1] = ~0ull;
+            }
+        }
+        SC::sync();
+        if (lane < T / 32 + 4) { // the tile 2-bit packed: word j = bases [32 j, 32 j + 32)
+            const uint32_t half = 32 * (lane & 1);
+            const uint64_t pl = lane / 2 < kQpt + 2 ? R.plane_lo[lane / 2] : 0, ph = lane / 2 < kQpt + 2 ? R.plane_hi[lane / 2] : 0;
+            R.packed[lane] = spread_bits((uint32_t)(pl >> half)) | (spread_bits((uint32_t)(ph >> half)) << 1);
+        }
+        SC::sync();
+        for (uint32_t j = lane; j < T + n_win - 1; j += 64) { // window keys of both strands (layout: window_minima_17)
+            const uint32_t m = (uint32_t)packed_mer(R.packed, j, w);
+            R.keys_f[j] = (hash_mmer32(m, ix.seed) << kTilePosBits) | j;
+            R.keys_r[j] = (hash_mmer32((uint32_t)kmer_rc(m, w), ix.seed) << kTilePosBits) | ((1u << kTilePosBits) - 1 - j);
+        }
+        SC::sync();
+        {
+            uint32_t wf[4], wr[4]; // window minima in place: every key is read before any is overwritten
+            window_minima_17(R.keys_f, lane, wf);
+            window_minima_17(R.keys_r, lane, wr);
+            SC::sync();
+            *reinterpret_cast<uint4 *>(&R.keys_f[4 * lane]) = uint4{wf[0], wf[1], wf[2], wf[3]};
+            *reinterpret_cast<uint4 *>(&R.keys_r[4 * lane]) = uint4{wr[0], wr[1], wr[2], wr[3]};
+            SC::sync();
+        }
+        // S0: one item per base position
+        uint64_t out_idx[kQpt];
+        uint32_t state[kQpt]; // 0 = no window here, 1 = window with a non-ACGT byte, 2 = valid k-mer (answer pending)
+        const bool slow = R.slow != 0;
+        uint64_t r = R.read0;
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            const uint32_t i = q * 64 + lane; // item == position inside the tile
+            const uint64_t b = B0 + i;
+            state[q] = 0;
+            out_idx[q] = 0;
+            uint64_t fw = 0, rc = 0;
+            Minimizer mn{0, 0};
+            if (b < n_bases) {
+                uint64_t rs, re, ko;
+                if (!slow) { // the read of position i: staged reads that start at or before it (from the start plane)
+                    const uint32_t rl = R.start_cum[q] + (uint32_t)__popcll(R.start_plane[q] & (~0ull >> (63 - lane)));
+                    rs = R.roff[rl]; re = R.roff[rl + 1]; ko = R.koff[rl];
+                } else {
+                    while (r + 1 < n_reads && read_offsets[r + 1] <= b) ++r;
+                    rs = read_offsets[r]; re = read_offsets[r + 1]; ko = kmer_offsets[r];
+                }
+                if (b >= rs && b + k <= re) {
+                    out_idx[q] = ko + (b - rs);
+                    const uint64_t inv = (R.plane_inv[q] >> lane) | (lane ? R.plane_inv[q + 1] << (64 - lane) : 0ull); // invalid flags of positions i, i+1, ...
+                    state[q] = (inv & ((1ull << k) - 1)) == 0 ? 2u : 1u;
+                }
+            }
+            const bool query = state[q] == 2;
+            if (query) {
+                fw = packed_mer(R.packed, i, k);
+                rc = kmer_rc(fw, k);
+                const uint32_t key = fw <= rc ? R.keys_f[i] : R.keys_r[i], low = key & ((1u << kTilePosBits) - 1); // minimum key of the window
+                mn.offset = fw <= rc ? low - i : (k - w) - ((1u << kTilePosBits) - 1 - low - i);
+                mn.word = ((fw <= rc ? fw : rc) >> (2 * mn.offset)) & kmer_mask(w);
+            }
+            tile_set_query<SC>(S, i, fw, rc, mn, k, w, query, false); // (runs are resolved per leader: no per-item line pattern)
+            if (state[q] == 1) { // non-ACGT window: reported, never queried
+                mz_k2upos sk = make_none();
+                sk.match = MZ_SKIPPED;
+                out[out_idx[q]] = sk;
+            }
+            tally.add(false, false, state[q] == 1);
+        }
+        tile_resolve<SC, true>(S, ix);
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            const bool pend = state[q] == 2;
+            mz_k2upos res = pend ? tile_result<SC>(S, ix, q * 64 + lane) : make_none();
+            if (pend) out[out_idx[q]] = res;
+            tally.add(pend && res.match != MZ_NO_MATCH, pend && res.match == MZ_NO_MATCH, false);
+        }
+        SC::sync();
+    }
+    tally.flush(counts);
+}
+
+// ------------------------------------------------------------------------------------
 // K: validate_self on the device (kphf/mod.rs:69-139).  One wave tile = 128 consecutive global base
 // positions, each queried as km (items 0..127) and km.swap() (items 128..255) through the tile
 // machinery; the expected (unitig, offset, length) comes from the plain `starts` array, which the
@@ -1592,7 +1781,12 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
     const char *lines_env = getenv("MZ_READS_LINES");
     const bool use_lines = lines_env ? lines_env[0] != '0' : d.n_entries >= (1ull << 28);
     if (!use_lines && v.mm.direct) v.front.lines = nullptr;
-    if (v.k == 31 && v.w == 15)
+    const char *rk = getenv("MZ_READS_KERNEL"); // "block": the workgroup-staged kernel also for (31, 15)
+    if (v.k == 31 && v.w == 15 && !(rk && rk[0] == 'b')) {
+        const uint64_t n_wave_tiles = (n_bases + kWaveTile - 1) / kWaveTile;
+        const dim3 wgrid(tile_grid(d, (n_wave_tiles + kBlock / 64 - 1) / (kBlock / 64), 8));
+        hipLaunchKernelGGL(k2u_reads_wave_kernel, wgrid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
+    } else if (v.k == 31 && v.w == 15)
         hipLaunchKernelGGL(k2u_reads_kernel<kKW3115>, grid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
                            n_reads, d_out, d_counts);
     else
