@@ -1798,7 +1798,10 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
     const char *rk = getenv("MZ_READS_KERNEL"); // "block": the workgroup-staged kernel also for (31, 15)
     if (v.k == 31 && v.w == 15 && !(rk && rk[0] == 'b')) {
         const uint64_t n_wave_tiles = (n_bases + kWaveTile - 1) / kWaveTile;
-        const dim3 wgrid(tile_grid(d, (n_wave_tiles + kBlock / 64 - 1) / (kBlock / 64), 8));
+        // workgroups per CU: 3 are resident; 24 give every slot eight shorter runs of tiles to even the finish out (measured 3: 31.0, 8: 30.3 --
+        // 2.67 rounds --, 24: 31.7, 96: 30.7 G windows/s on s-txome; every wave starts with a search for its first read)
+        const char *ge = getenv("MZ_READS_GRID");
+        const dim3 wgrid(tile_grid(d, (n_wave_tiles + kBlock / 64 - 1) / (kBlock / 64), ge && atoi(ge) > 0 ? (unsigned)atoi(ge) : 24u));
         hipLaunchKernelGGL(k2u_reads_wave_kernel, wgrid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
     } else if (v.k == 31 && v.w == 15)
         hipLaunchKernelGGL(k2u_reads_kernel<kKW3115>, grid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
