@@ -659,6 +659,24 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     }
     SC::sync();
     if constexpr (kStopAfter == 2) return;
+    // ---- S4 (heavy buckets, sshash.rs:415-433), first half: eight lanes fetch the k-mer's 128-byte skew-table bucket with one
+    //          coalesced 16-byte load each.  The requests of the first eight heavy items of the wave go out HERE, ahead of S3, so
+    //          that the few items S3 and S4 serve in a tile (about three each at S-human) cost the tile ONE dependent round
+    //          trip to HBM instead of two.
+    struct SkewReq { ulonglong2 sl; uint32_t fp, item; };
+    const uint32_t n_heavy = (ix.has_skew && ix.skew.n_buckets != 0) ? S.cnt_skew : 0u; // uniform
+    const uint32_t s4_lane = t & 63, s4_sub = s4_lane & 7, s4_grp = s4_lane >> 3;
+    auto skew_issue = [&](uint32_t j) {
+        SkewReq rq;
+        rq.item = j < n_heavy ? (uint32_t)S.list_b[j] : ~0u;
+        const uint64_t fw = rq.item != ~0u ? S.fw[rq.item] : 0ull, rc = kmer_rc(fw, k);
+        uint64_t hb;
+        skew_home(fw < rc ? fw : rc, ix.skew.n_buckets, ix.skew.fp_mask, hb, rq.fp);
+        rq.sl = *reinterpret_cast<const ulonglong2 *>(ix.skew.buckets + (rq.item != ~0u ? hb : 0ull) * kSkewSlots + 2 * s4_sub);
+        return rq;
+    };
+    SkewReq s4_first{};
+    if (n_heavy != 0) s4_first = skew_issue((t >> 6) * 8 + s4_grp);
     // ---- S3: bucket entries of the whole tile as ONE flat sequence (exclusive scan of the bucket sizes, items blocked by
     //          thread), so lanes are busy whatever the bucket-size distribution.  Chunks of kEpt consecutive entries per lane;
     //          the owner of an entry comes from a max-scan over "bucket head" marks (the item index, dropped at the slot of
@@ -771,42 +789,30 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     }
     SC::sync();
     if constexpr (kStopAfter == 3) return;
-    // ---- S4: heavy buckets go through the skew index (sshash.rs:415-433): ONE gather of the k-mer's 128-byte home bucket;
-    //          the slot with its fingerprint gives the candidate position for S5.  More than one such slot, or a full
-    //          bucket (its keys may have overflowed), raises the item's flag: if S5 cannot verify the candidate it falls
-    //          back to the exact walk, which also searches the overflow list.
-    if (S.cnt_skew != 0) { // uniform
-        const uint32_t ns = S.cnt_skew;
-        SC::sync();
-        if (ix.has_skew && ix.skew.n_buckets != 0) {
-            for (uint32_t j = t; j < ns; j += SC::NT) {
-                const uint32_t i = S.list_b[j];
-                const uint64_t fw = S.fw[i], rc = kmer_rc(fw, k);
-                uint64_t hb;
-                uint32_t fp;
-                skew_home(fw < rc ? fw : rc, ix.skew.n_buckets, ix.skew.fp_mask, hb, fp);
-                const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(ix.skew.buckets + hb * kSkewSlots);
-                ulonglong2 sl[kSkewSlots / 2];
-#pragma unroll
-                for (uint32_t q = 0; q < kSkewSlots / 2; ++q) sl[q] = v[q];
-                uint64_t cand = kBestNone;
-                uint32_t n_match = 0;
-                bool full = true;
-#pragma unroll
-                for (int q = (int)kSkewSlots - 1; q >= 0; --q) { // downwards: `cand` ends as the FIRST matching slot
-                    const uint64_t e = (q & 1) ? sl[q >> 1].y : sl[q >> 1].x;
-                    if (e == kSkewEmpty) full = false;
-                    else if ((uint32_t)(e >> kSkewPosBits) == fp) { cand = e & ((1ull << kSkewPosBits) - 1); ++n_match; }
-                }
-                // a full bucket may have spilled keys into the overflow list, and the one matching slot may then be a mere
-                // fingerprint collision: flag every item of a full bucket, so a failed verification goes to the exact walk
-                if (full || n_match > 1) {
-                    S.qinfo[i] |= kQMulti;
-                    if (n_match == 0) cand = 0; // any valid position: its verification fails and the flag sends the item to the exact walk
-                }
-                S.best[i] = cand;
+    // ---- S4, second half: the slot with the k-mer's fingerprint gives the candidate position for S5 (slots run in lane order,
+    //          two per lane: the first matching one counts).  More than one such slot, or a full bucket (its keys may have
+    //          overflowed, and the one matching slot may then be a mere fingerprint collision), raises the item's flag: if S5
+    //          cannot verify the candidate it falls back to the exact walk, which also searches the overflow list.
+    if (n_heavy != 0) { // uniform
+        const unsigned long long grp_mask = 0xFFull << (s4_lane & ~7u);
+        auto skew_finish = [&](const SkewReq &rq) {
+            const uint64_t e0 = rq.sl.x, e1 = rq.sl.y;
+            const bool emp0 = e0 == kSkewEmpty, emp1 = e1 == kSkewEmpty;
+            const bool m0 = !emp0 && (uint32_t)(e0 >> kSkewPosBits) == rq.fp, m1 = !emp1 && (uint32_t)(e1 >> kSkewPosBits) == rq.fp;
+            const unsigned long long b0 = __ballot(m0) & grp_mask, b1 = __ballot(m1) & grp_mask, be = __ballot(emp0 || emp1) & grp_mask;
+            if (rq.item == ~0u) return;
+            const uint32_t n_match = (uint32_t)(__popcll(b0) + __popcll(b1));
+            if (const unsigned long long any = b0 | b1) {
+                const uint32_t fl = (uint32_t)__ffsll((long long)any) - 1;
+                if (s4_lane == fl) S.best[rq.item] = (((b0 >> fl) & 1) ? e0 : e1) & ((1ull << kSkewPosBits) - 1);
             }
-        }
+            if (s4_sub == 0 && (be == 0 || n_match > 1)) {
+                S.qinfo[rq.item] |= kQMulti;
+                if (n_match == 0) S.best[rq.item] = 0; // any valid position: its verification fails and the flag sends the item to the exact walk
+            }
+        };
+        skew_finish(s4_first);
+        for (uint32_t base = (t >> 6) * 8 + (SC::NT / 64) * 8; base < n_heavy; base += (SC::NT / 64) * 8) skew_finish(skew_issue(base + s4_grp));
         SC::sync();
     }
     if constexpr (kStopAfter == 4) return;
