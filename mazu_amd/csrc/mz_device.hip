@@ -105,6 +105,9 @@ constexpr int kStopAfter = MZ_STOP_AFTER;
 #ifndef MZ_REC_BATCH
 #define MZ_REC_BATCH 1
 #endif
+#ifndef MZ_ROW_S0
+#define MZ_ROW_S0 1 // wave-scoped point kernel: stage S0 row by row inside SF (see tile_resolve)
+#endif
 #ifndef MZ_WAVES_PER_EU
 #define MZ_WAVES_PER_EU 4
 #endif
@@ -336,9 +339,22 @@ __device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, 
 
 // kRuns: consecutive items of the tile tend to carry the same minimizer (the windows of a read): the direct-address stage then
 // reads one record per RUN of equal keys instead of one per item
-template <class SC, bool kRuns = false>
-__device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexView &ix) {
+// kRowS0: a callable s0(q) that computes stage S0 of the items q * 64 + lane (wave scope only).  With minimizer lines, batch b
+// of stage SF needs only row b of the tile, so the rows are prepared one batch AHEAD: the S0 arithmetic of row b + 1 runs while
+// the lines of row b are in flight.  Callers without it fill the whole tile before they call tile_resolve.
+struct NoRowS0 { __device__ __forceinline__ void operator()(int) const {} };
+template <class SC, bool kRuns = false, class RowS0 = NoRowS0>
+__device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexView &ix, RowS0 s0 = RowS0{}) {
     const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
+    constexpr bool kHasS0 = !std::is_same<RowS0, NoRowS0>::value;
+    static_assert(!kHasS0 || (SC::NT == 64 && !kRuns), "row-wise S0 is for the wave-scoped point kernel");
+    const bool sf_rows = kHasS0 && ix.front.lines != nullptr; // uniform: rows are prepared inside SF
+    if constexpr (kHasS0) {
+        if (!sf_rows || kStopAfter == 1) {
+#pragma unroll
+            for (int q = 0; q < kQpt; ++q) s0(q);
+        }
+    }
     SC::sync();
     if constexpr (kStopAfter == 1) return;
     // ---- SF: minimizer lines.  ONE gather answers membership and, for most keys, hands over the bucket's entries with their
@@ -360,6 +376,9 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
         const uint32_t gl = 2 * w - ix.front.t, line_mask = (uint32_t)(ix.front.n_lines - 1); // word = tag | line index | low g bits: tag starts at bit gl
         const uint32_t wave_q0 = (t >> 6) * (64 * kQpt);      // first item of this wave's share of the tile
         const unsigned long long grp_mask = ((1ull << kLpq) - 1) << (lane & ~(kLpq - 1)), low_mask = grp_mask & ((1ull << lane) - 1); // my query's lanes / those before me
+        static_assert(!kHasS0 || kFR * kQpr == 64, "one SF batch per row of the tile");
+        if constexpr (kHasS0) { s0(0); SC::sync(); }
+#pragma unroll
         for (uint32_t r0 = 0; r0 < kRounds; r0 += kFR) { // (a rolling window of requests instead of batches measured the same: the gathers are bandwidth-bound)
             ulonglong2 sl[kFR];
             uint32_t pat[kFR];
@@ -369,6 +388,9 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 const uint32_t key = (uint32_t)kp;
                 pat[a] = (uint32_t)(kp >> 32) | (front_keyfield(key, g, gl) << kFrontKeyShift);
                 sl[a] = *reinterpret_cast<const ulonglong2 *>(ix.front.lines + (uint64_t)((key >> g) & line_mask) * kFrontSlots + 2 * sub);
+            }
+            if constexpr (kHasS0) {
+                if (r0 / kFR + 1 < (uint32_t)kQpt) { s0((int)(r0 / kFR) + 1); SC::sync(); } // the next row, while this row's lines are in flight
             }
 #pragma unroll
             for (int a = 0; a < kFR; ++a) {
@@ -950,14 +972,19 @@ __global__ __launch_bounds__(kBlock, MZ_WAVES_PER_EU) void k2u_wave_kernel(Index
             const uint32_t i = q * SC::NT + t;
             fwq[q] = fw_words[base + (i < n_valid ? i : 0u)];
         }
-#pragma unroll
-        for (int q = 0; q < kQpt; ++q) {
+        auto s0_row = [&](int q) {
             const uint32_t i = q * SC::NT + t;
             const uint64_t fw = i < n_valid ? (fwq[q] & kmask) : 0;
             const uint64_t rc = kmer_rc(fw, k);
             tile_set_query<SC>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), k, w, i < n_valid, ix.front.lines != nullptr);
-        }
+        };
+#if MZ_ROW_S0
+        tile_resolve<SC, false>(S, ix, s0_row);
+#else
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) s0_row(q);
         tile_resolve<SC>(S, ix);
+#endif
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * SC::NT + t;
