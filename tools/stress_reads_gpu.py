@@ -13,6 +13,7 @@ from oracle import oracle as O
 
 rng = np.random.default_rng(4242)
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+plant = "--no-plant" not in sys.argv  # without the repeat family the sets have no duplicate k-mers: every window is compared bit for bit
 letters = np.frombuffer(b"ACGT", dtype=np.uint8)
 bad = 0
 for c in range(n_cfg):
@@ -31,7 +32,7 @@ for c in range(n_cfg):
     codes, starts = H.random_unitigs(seed, int(rng.integers(100, 1200)), float(rng.choice([60, 200, 800])), k, max_len=4000)
     total = int(starts[-1])
     motif = rng.integers(0, 4, int(rng.integers(k + 5, 120)), dtype=np.uint8)
-    for _ in range(int(rng.integers(0, 300))):
+    for _ in range(int(rng.integers(0, 300)) if plant else 0):
         p = int(rng.integers(0, max(1, total - len(motif))))
         m = motif.copy()
         mut = rng.random(len(m)) < 0.08
