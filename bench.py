@@ -230,13 +230,17 @@ def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
     counts.zero_()
     torch.cuda.synchronize(dev)
     D.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for a, b in ev:
+        a.record(stream)
         step()
+        b.record(stream)
     D.allreduce_counts(counts)
     torch.cuda.synchronize(dev)
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    kernel_s = float(np.mean([a.elapsed_time(b) for a, b in ev])) / 1e3
     n_hit, n_miss, n_skip = counts.cpu().tolist()
     if rank == 0:
         total = n_win * world * args.steps
@@ -261,6 +265,15 @@ def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
             res["cpu_baseline"] = {"value": round(len(want) / dt / 1e6, 3), "unit": "M k-mers/s", "cores": 1, "kind": "port",
                                    "sample": f"first {n_s} reads, single thread, StreamingK2U walk (bin/kphf/main.rs:299-312)",
                                    "results_identical_to_gpu": same}
+            # algorithmic bytes of the streaming walk in the reference layout: a cold window costs the whole chain (B_ALG), a warm one
+            # a quarter byte of sequence and its 16-byte result; f_cold is counted by the oracle on the sample (match 3 = skipped window)
+            f_cold = orc.last_reads_cold / max(1, len(want) - int((want["match"] == 3).sum()))
+            b_win = B_ALG * f_cold + 17.0 * (1.0 - f_cold)
+            achieved = n_win * b_win / kernel_s / 1e9
+            res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "kernel": "k2u_reads_wave_kernel" if args.w == 15 else "k2u_reads_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4),
+                               "algorithmic_bytes_per_window": round(b_win, 1), "f_cold": round(f_cold, 4)}
             assert same, "GPU read results differ from the oracle's streaming walk"
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -61,6 +61,8 @@ def lib():
         L.orc_dict_n_duplicates.argtypes = [p]
         L.orc_k2u_batch.argtypes = [p, p, u64, p, p, C.c_int, C.c_int]
         L.orc_k2u_reads.argtypes = [p, p, p, u64, p, C.c_int, p, p]
+        L.orc_reads_cold_lookups.restype = u64
+        L.orc_reads_cold_lookups.argtypes = []
         L.orc_validate_self.restype = u64
         L.orc_validate_self.argtypes = [p, C.c_int]
         for name in ("orc_n_unitigs", "orc_n_kmers", "orc_sum_unitigs_len", "orc_n_minimizers",
@@ -144,6 +146,7 @@ class OracleSSHash:
         counts = np.zeros(3, dtype=np.uint64)
         lib().orc_k2u_reads(self.h, _ptr(bases), _ptr(ro), len(ro) - 1, _ptr(ko), 1 if streaming else 0,
                             _ptr(out), _ptr(counts))
+        self.last_reads_cold = int(lib().orc_reads_cold_lookups())  # windows that took the whole chain (k2u_cold)
         return out, ko, counts
 
     def word_touches(self, fw_words):

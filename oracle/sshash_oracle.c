@@ -810,9 +810,11 @@ void orc_k2u_batch(const orc_index *ix, const uint64_t *fw_words, uint64_t n, or
 
 /* index/caching.rs:12-103 StreamingK2U */
 typedef struct { int is_warm; orc_k2upos prev; } orc_stream;
+static uint64_t g_reads_cold; /* cold lookups of the last orc_k2u_reads call (single-threaded walk) */
 
 static int k2u_cold(const orc_index *ix, orc_stream *st, uint64_t fw, orc_k2upos *out) { /* :99-103 */
     orc_k2upos r;
+    ++g_reads_cold;
     if (!orc_k2u(ix, fw, &r)) { *out = r; return 0; } /* `?` : state untouched on a miss */
     st->prev = r; st->is_warm = 1; *out = r;
     return 1;
@@ -842,6 +844,7 @@ void orc_k2u_reads(const orc_index *ix, const uint8_t *bases, const uint64_t *re
     unsigned k = ix->us.k;
     uint64_t mask = (1ull << (2 * k)) - 1, n_hit = 0, n_miss = 0, n_skip = 0;
     orc_stream st; memset(&st, 0, sizeof st);
+    g_reads_cold = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
         uint64_t s = read_offsets[r], e = read_offsets[r + 1];
         uint64_t fw = 0; unsigned valid = 0;
@@ -852,6 +855,7 @@ void orc_k2u_reads(const orc_index *ix, const uint8_t *bases, const uint64_t *re
                 orc_k2upos *o = &out[kmer_offsets[r] + (i + 1 - k - s)];
                 if (valid >= k) {
                     int hit = streaming ? k2u_streaming(ix, &st, fw, o) : orc_k2u(ix, fw, o);
+                    if (!streaming) ++g_reads_cold;
                     if (hit) ++n_hit; else ++n_miss;
                 } else { o->unitig_id = o->pos = o->unitig_len = 0; o->match = ORC_SKIPPED; ++n_skip; }
             }
@@ -859,6 +863,10 @@ void orc_k2u_reads(const orc_index *ix, const uint8_t *bases, const uint64_t *re
     }
     if (counts) { counts[0] = n_hit; counts[1] = n_miss; counts[2] = n_skip; }
 }
+
+/* windows of the last orc_k2u_reads call that went through the whole k2u chain (k2u_cold, caching.rs:99-103; every window
+ * when streaming == 0); the others were answered by the warm step from the previous position */
+uint64_t orc_reads_cold_lookups(void) { return g_reads_cold; }
 
 /* kphf/mod.rs:69-103 K2U::validate_self: every k-mer of every unitig, both orientations.
  * Returns the number of failed assertions (0 == the reference's test passes). */
