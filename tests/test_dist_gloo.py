@@ -8,6 +8,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -95,3 +96,26 @@ def test_bench_gpus_n_fails_loudly_without_n_gpus():
     r = _run_bench({"MZ_DIST_BACKEND": "nccl"}, "--gpus", "2", "--launch-check")
     assert r.returncode != 0
     assert "GPU(s) visible" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["point", "reads"])
+def test_bench_two_ranks_on_one_card(mode):
+    """the whole N = 2 bench path on the GPU -- two self-launched ranks, a replica built by each, sharded batches, the final
+    all-reduce of the tallies, max-over-ranks timing -- with gloo standing in for RCCL so that both ranks can share one card"""
+    import json
+    argv = ["--gpus", "2", "--workload", "s-yeast", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra-mixes"]
+    if mode == "reads":
+        argv += ["--mode", "reads", "--n-reads", "20000"]
+    r = _run_bench({"MZ_DIST_BACKEND": "gloo"}, *argv)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    if mode == "point":
+        per_gpu = res["config"]["queries_per_gpu_per_step"]
+        assert abs(res["value"] * 1e6 * res["ms_per_step"] / 1e3 - 2 * per_gpu) < 0.01 * per_gpu  # both ranks' queries are counted
+        assert 0.49 < res["hit_fraction"] < 0.51  # the all-reduced tallies cover both shards (the launcher asserts hit + miss == all queries)
+    else:
+        assert res["config"]["windows_per_gpu_per_step"] == 20000 * 120 and res["hit_fraction"] > 0.5
