@@ -270,8 +270,10 @@ def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
             f_cold = orc.last_reads_cold / max(1, len(want) - int((want["match"] == 3).sum()))
             b_win = B_ALG * f_cold + 17.0 * (1.0 - f_cold)
             achieved = n_win * b_win / kernel_s / 1e9
+            tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")  # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload only)
+            rec = json.load(open(tf)).get(f"reads:{args.workload}:{n_win}") if os.path.exists(tf) and args.err_frac == 0.5 else None
             res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec["hbm_bytes_per_launch"] if rec else None,
                                "kernel": "k2u_reads_wave_kernel" if args.w == 15 else "k2u_reads_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4),
                                "algorithmic_bytes_per_window": round(b_win, 1), "f_cold": round(f_cold, 4)}
             assert same, "GPU read results differ from the oracle's streaming walk"

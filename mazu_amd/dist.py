@@ -7,11 +7,12 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None, device=None):
-    """initialise torch.distributed from the torchrun environment; returns (rank, world)"""
+def init(backend=None, device=None, force=False):
+    """initialise torch.distributed from the torchrun environment; returns (rank, world).  A single process needs no group
+    (`force` makes one anyway: the one-rank RCCL check of the GPU tests)"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {}
         if backend == "nccl" and device is not None:

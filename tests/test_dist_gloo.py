@@ -119,3 +119,31 @@ def test_bench_two_ranks_on_one_card(mode):
         assert 0.49 < res["hit_fraction"] < 0.51  # the all-reduced tallies cover both shards (the launcher asserts hit + miss == all queries)
     else:
         assert res["config"]["windows_per_gpu_per_step"] == 20000 * 120 and res["hit_fraction"] > 0.5
+
+
+@pytest.mark.gpu
+def test_rccl_group_of_one_rank_reduces_the_tallies():
+    """the backend the multi-GPU runs use ("nccl" = RCCL, bound to the rank's device) initialises on this box and carries the path's
+    collectives -- sum of the tallies, max of the times, barrier -- on device tensors; with one GPU the group has one rank"""
+    import subprocess
+    code = f"""
+import os, sys, torch
+sys.path.insert(0, {H.ROOT!r})
+os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="{_free_port()}")
+from mazu_amd import dist as D
+import torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+assert D.init("nccl", dev, force=True) == (0, 1) and dist.get_backend() == "nccl"
+c = torch.tensor([5, 7, 0], dtype=torch.int64, device=dev)
+D._reduce(c, dist.ReduceOp.SUM)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+D._reduce(t, dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize(dev)
+assert c.tolist() == [5, 7, 0] and t.item() == 1.5
+dist.destroy_process_group()
+print("rccl ok", flush=True)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
