@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <exception>
 #include <cstdlib>
+#include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 #include <new>
@@ -21,18 +23,20 @@ struct mz_unitig_set {
     UnitigSet us;
 };
 
-// Staging context of one host-pointer call (mz_sshash_k2u_batch): a stream, two pinned chunk buffers and their device
-// twins.  Pooled per handle (a call takes one, concurrent callers get their own), freed by mz_sshash_free.
+// Staging context of one host-pointer call (mz_sshash_k2u_batch, mz_sshash_k2u_reads): per slot a stream, a pinned chunk
+// buffer each way and their device twins.  Pooled per handle (a call takes one, concurrent callers get their own), freed by
+// mz_sshash_free.
+constexpr int kPipeSlots = 3; // chunk c is staged while chunk c-1 is on the GPU and chunk c-2 is drained
 struct HostPipe {
     int device = -1;
     uint64_t cap = 0; // queries per chunk
-    hipStream_t stream[2] = {nullptr, nullptr}; // one per slot: the upload of chunk c overlaps the download of chunk c-1
-    hipEvent_t done[2] = {nullptr, nullptr};
-    uint64_t *h_in[2] = {nullptr, nullptr}, *d_in[2] = {nullptr, nullptr};
-    mz_k2upos *h_out[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
+    hipStream_t stream[kPipeSlots] = {}; // one per slot: the upload of a chunk overlaps the download of the one before
+    hipEvent_t done[kPipeSlots] = {};
+    uint64_t *h_in[kPipeSlots] = {}, *d_in[kPipeSlots] = {};
+    mz_k2upos *h_out[kPipeSlots] = {}, *d_out[kPipeSlots] = {};
     mz_counts *d_counts = nullptr, *h_counts = nullptr;
     void release() {
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < kPipeSlots; ++j) {
             if (h_in[j]) (void)hipHostFree(h_in[j]);
             if (h_out[j]) (void)hipHostFree(h_out[j]);
             if (d_in[j]) (void)hipFree(d_in[j]);
@@ -257,16 +261,16 @@ int mz_sshash_k2u_batch_compact_device(mz_sshash *ix, const uint64_t *d_fw_words
 }
 
 // chunk size of the host-pointer pipeline: 16 MB of queries / 32 MB of results per slot stay cache-resident on the host
-// (1 M: 1.41, 2 M: 1.48, 4 M: 1.26, 8 M: 1.01 G k-mers/s end to end; MZ_HOST_CHUNK overrides)
+// (1 M: 2.54, 2 M: 2.69, 4 M: 2.56-2.70, 8 M: 2.54 G k-mers/s end to end into a reused result array; MZ_HOST_CHUNK overrides)
 static uint64_t host_chunk_queries() {
     const char *e = std::getenv("MZ_HOST_CHUNK"); // read per call: tests shrink it to walk the multi-chunk path
     long long v = e ? atoll(e) : 0;
     return (uint64_t)(v > 0 ? v : (2ll << 20));
 }
 // copies with a few host threads (one memcpy stream is ~10 GB/s, the PCIe link wants ~50)
-static void parallel_copy(void *dst, const void *src, uint64_t bytes) {
-    const uint64_t kMin = 4ull << 20;
-    int nt = (int)std::min<uint64_t>(std::min<int>(hw_threads(), 8), bytes / kMin);
+static void parallel_copy(void *dst, const void *src, uint64_t bytes, int max_threads = 8) {
+    const uint64_t kMin = 2ull << 20;
+    int nt = (int)std::min<uint64_t>(std::max(1, std::min<int>(hw_threads(), max_threads)), bytes / kMin);
     if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
     std::vector<std::thread> th;
     const uint64_t per = ((bytes + nt - 1) / nt + 4095) & ~4095ull;
@@ -293,7 +297,7 @@ static int pipe_acquire(mz_sshash *ix, uint64_t want, HostPipe **out) {
         p->release();
         hipError_t e = hipSuccess;
         bool ok = true;
-        for (int j = 0; j < 2 && ok; ++j)
+        for (int j = 0; j < kPipeSlots && ok; ++j)
             ok = (e = hipStreamCreateWithFlags(&p->stream[j], hipStreamNonBlocking)) == hipSuccess && // own streams: concurrent host threads do not serialise
                  (e = hipEventCreateWithFlags(&p->done[j], hipEventDisableTiming)) == hipSuccess &&
                  (e = hipHostMalloc((void **)&p->h_in[j], want * 8, hipHostMallocDefault)) == hipSuccess &&
@@ -317,8 +321,101 @@ static void pipe_release(mz_sshash *ix, HostPipe *p) {
     ix->idle_pipes.push_back(p);
 }
 
-// Host pointers in, host pointers out.  Chunks go through two pinned slots: while the GPU works on chunk c (H2D, kernel,
-// D2H on one stream) the calling thread drains the results of chunk c-1 into `out` and stages the queries of chunk c+1.
+
+// Drives `n_chunks` chunks through the slots of a staging pipe.  stage(c, slot) fills the slot's pinned input and puts upload,
+// kernel and download on the slot's stream (MZ_OK or an error code, message set); drain(c, slot) copies the slot's pinned
+// results to the caller.  The tally is cleared first and copied to p->h_counts behind the last chunk.  Calls of up to two
+// chunks run on the calling thread alone (stage c, then drain c - 1).  Longer ones drain on a helper thread, so that the
+// calling thread stages chunk c while the GPU holds chunk c - 1 and the helper empties chunk c - 2: the link then carries
+// uploads and downloads at the same time and neither host copy waits for the other.
+struct PipeCopyThreads { int stage, drain; };
+static PipeCopyThreads pipe_copy_threads(bool threaded) {
+    const int hw = hw_threads();
+    if (!threaded) return {8, 8};
+    return {std::max(2, std::min(8, hw / 3)), std::max(2, std::min(12, hw - hw / 3 - 1))}; // results are twice the bytes of the queries
+}
+} // extern "C" (a template needs C++ linkage)
+template <class Stage, class Drain>
+static int run_pipe(HostPipe *p, uint64_t n_chunks, const char *what, Stage stage, Drain drain) {
+    hipError_t e = hipMemsetAsync(p->d_counts, 0, sizeof(mz_counts), p->stream[0]);
+    if (e == hipSuccess) e = hipEventRecord(p->done[0], p->stream[0]);
+    for (int j = 1; j < kPipeSlots && (uint64_t)j < n_chunks && e == hipSuccess; ++j) e = hipStreamWaitEvent(p->stream[j], p->done[0], 0); // every stream in use starts after the tally is cleared
+    int rc = MZ_OK;
+    // stage + the pipe's own bookkeeping behind a chunk
+    auto put = [&](uint64_t c) -> int {
+        const int slot = (int)(c % kPipeSlots);
+        hipStream_t st = p->stream[slot];
+        int r = stage(c, slot);
+        if (r != MZ_OK) return r;
+        hipError_t pe = hipSuccess;
+        if (c + 1 == n_chunks) { // the tally is complete once the last kernels of the other slots are done too
+            for (int j = 1; j < kPipeSlots && pe == hipSuccess; ++j)
+                if (c >= (uint64_t)j) pe = hipStreamWaitEvent(st, p->done[(c - j) % kPipeSlots], 0);
+            if (pe == hipSuccess) pe = hipMemcpyAsync(p->h_counts, p->d_counts, sizeof(mz_counts), hipMemcpyDeviceToHost, st);
+        }
+        if (pe == hipSuccess) pe = hipEventRecord(p->done[slot], st);
+        if (pe != hipSuccess) { set_error("HIP error in %s: %s", what, hipGetErrorString(pe)); return MZ_EHIP; }
+        return MZ_OK;
+    };
+    auto take = [&](uint64_t c) -> int {
+        const int slot = (int)(c % kPipeSlots);
+        hipError_t te = hipEventSynchronize(p->done[slot]);
+        if (te != hipSuccess) { set_error("HIP error in %s: %s", what, hipGetErrorString(te)); return MZ_EHIP; }
+        drain(c, slot);
+        return MZ_OK;
+    };
+    if (e != hipSuccess) {
+        set_error("HIP error in %s: %s", what, hipGetErrorString(e));
+        rc = MZ_EHIP;
+    } else if (n_chunks <= 2 || hw_threads() < 4) {
+        for (uint64_t c = 0; c <= n_chunks && rc == MZ_OK; ++c) {
+            if (c < n_chunks) rc = put(c);
+            if (rc == MZ_OK && c >= 1) rc = take(c - 1);
+        }
+    } else {
+        std::mutex m;
+        std::condition_variable cv;
+        uint64_t staged = 0, drained = 0; // chunks put on the GPU / copied out, guarded by m
+        int rc_drain = MZ_OK;
+        bool stop = false;
+        std::string drain_error;
+        std::thread helper([&] {
+            (void)hipSetDevice(p->device);
+            for (uint64_t c = 0; c < n_chunks; ++c) {
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return staged > c || stop; });
+                    if (staged <= c) return; // the stager gave up
+                }
+                const int r = take(c);
+                std::lock_guard<std::mutex> lk(m);
+                if (r != MZ_OK) { rc_drain = r; drain_error = mz_last_error(); stop = true; cv.notify_all(); return; } // the message is thread-local: hand it over
+                drained = c + 1;
+                cv.notify_all();
+            }
+        });
+        for (uint64_t c = 0; c < n_chunks && rc == MZ_OK; ++c) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return drained + kPipeSlots > c || stop; }); // the slot's previous chunk has left it
+                if (stop) break;
+            }
+            rc = put(c);
+            std::lock_guard<std::mutex> lk(m);
+            if (rc != MZ_OK) stop = true; else staged = c + 1;
+            cv.notify_all();
+        }
+        helper.join();
+        if (rc == MZ_OK && rc_drain != MZ_OK) { rc = rc_drain; set_error("%s", drain_error.c_str()); }
+    }
+    if (rc != MZ_OK)
+        for (int j = 0; j < kPipeSlots; ++j) (void)hipStreamSynchronize(p->stream[j]); // nothing may still be in flight when the pipe is reused
+    return rc;
+}
+extern "C" {
+
+// Host pointers in, host pointers out, through the staging pipe (run_pipe): a chunk is uploaded, looked up and downloaded on its
+// slot's stream while its neighbours are staged and drained by the host.
 int mz_sshash_k2u_batch(mz_sshash *ix, const uint64_t *fw_words, uint64_t n, mz_k2upos *out, mz_counts *counts) {
     DeviceGuard guard;
     if (!ix || (n && (!fw_words || !out))) { set_error("null argument"); return MZ_EINVAL; }
@@ -331,37 +428,28 @@ int mz_sshash_k2u_batch(mz_sshash *ix, const uint64_t *fw_words, uint64_t n, mz_
     HostPipe *p = nullptr;
     if ((rc = pipe_acquire(ix, chunk, &p)) != MZ_OK) return rc;
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
-    hipError_t e = hipMemsetAsync(p->d_counts, 0, sizeof(mz_counts), p->stream[0]);
-    if (e == hipSuccess) e = hipEventRecord(p->done[0], p->stream[0]);
-    if (e == hipSuccess) e = hipStreamWaitEvent(p->stream[1], p->done[0], 0); // both streams start after the tally is cleared
+    const PipeCopyThreads ct = pipe_copy_threads(n_chunks > 2);
     auto span = [&](uint64_t c, uint64_t &b, uint64_t &len) { b = c * chunk; len = std::min<uint64_t>(chunk, n - b); };
-    for (uint64_t c = 0; c <= n_chunks && e == hipSuccess && rc == MZ_OK; ++c) {
-        const int slot = (int)(c & 1);
-        hipStream_t st = p->stream[slot];
-        uint64_t b, len;
-        if (c < n_chunks) { // stage chunk c (its slot was drained two iterations ago)
+    rc = run_pipe(p, n_chunks, "k2u_batch",
+        [&](uint64_t c, int slot) -> int {
+            uint64_t b, len;
             span(c, b, len);
-            parallel_copy(p->h_in[slot], fw_words + b, len * 8);
-            if ((e = hipMemcpyAsync(p->d_in[slot], p->h_in[slot], len * 8, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-            if ((rc = launch_k2u_batch(*ix->dev, p->d_in[slot], len, p->d_out[slot], p->d_counts, st)) != MZ_OK) break;
-            if ((e = hipMemcpyAsync(p->h_out[slot], p->d_out[slot], len * sizeof(mz_k2upos), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
-            if (c + 1 == n_chunks) { // the tally is complete once the other slot's last kernel is done too
-                if (c >= 1 && (e = hipStreamWaitEvent(st, p->done[slot ^ 1], 0)) != hipSuccess) break;
-                if ((e = hipMemcpyAsync(p->h_counts, p->d_counts, sizeof(mz_counts), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+            hipStream_t st = p->stream[slot];
+            parallel_copy(p->h_in[slot], fw_words + b, len * 8, ct.stage);
+            hipError_t e = hipMemcpyAsync(p->d_in[slot], p->h_in[slot], len * 8, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) {
+                const int r = launch_k2u_batch(*ix->dev, p->d_in[slot], len, p->d_out[slot], p->d_counts, st);
+                if (r != MZ_OK) return r;
+                e = hipMemcpyAsync(p->h_out[slot], p->d_out[slot], len * sizeof(mz_k2upos), hipMemcpyDeviceToHost, st);
             }
-            if ((e = hipEventRecord(p->done[slot], st)) != hipSuccess) break;
-        }
-        if (c >= 1) { // drain chunk c-1 while chunk c is on the GPU
-            span(c - 1, b, len);
-            if ((e = hipEventSynchronize(p->done[slot ^ 1])) != hipSuccess) break;
-            parallel_copy(out + b, p->h_out[slot ^ 1], len * sizeof(mz_k2upos));
-        }
-    }
-    if (e != hipSuccess) {
-        set_error("HIP error in k2u_batch: %s", hipGetErrorString(e));
-        rc = MZ_EHIP;
-    }
-    if (rc != MZ_OK) { (void)hipStreamSynchronize(p->stream[0]); (void)hipStreamSynchronize(p->stream[1]); } // nothing may still be in flight when the pipe is reused
+            if (e != hipSuccess) { set_error("HIP error in k2u_batch: %s", hipGetErrorString(e)); return MZ_EHIP; }
+            return MZ_OK;
+        },
+        [&](uint64_t c, int slot) {
+            uint64_t b, len;
+            span(c, b, len);
+            parallel_copy(out + b, p->h_out[slot], len * sizeof(mz_k2upos), ct.drain);
+        });
     if (rc == MZ_OK && counts) *counts = *p->h_counts;
     pipe_release(ix, p);
     return rc;
@@ -397,7 +485,7 @@ int mz_sshash_k2u_reads_device(mz_sshash *ix, const uint8_t *d_bases, uint64_t n
                             (hipStream_t)stream);
 }
 
-// Reads through the two-slot staging pipe: a chunk is a run of whole reads whose windows fit the result slot and whose
+// Reads through the staging pipe (run_pipe): a chunk is a run of whole reads whose windows fit the result slot and whose
 // bases + offset tables fit the query slot.  Slot layout: [read offsets (nr+1)][k-mer offsets (nr+1)][bases], rebased to
 // the chunk.  Returns MZ_EUNSUPPORTED_INTERNAL when a single read is too long for a chunk (the caller then takes the
 // unchunked path).
@@ -425,41 +513,31 @@ static int k2u_reads_pipelined(mz_sshash *ix, const uint8_t *bases, const uint64
     int rc = pipe_acquire(ix, cap, &p);
     if (rc != MZ_OK) return rc;
     const uint64_t n_chunks = cut.size() - 1;
-    hipError_t e = hipMemsetAsync(p->d_counts, 0, sizeof(mz_counts), p->stream[0]);
-    if (e == hipSuccess) e = hipEventRecord(p->done[0], p->stream[0]);
-    if (e == hipSuccess) e = hipStreamWaitEvent(p->stream[1], p->done[0], 0);
-    for (uint64_t c = 0; c <= n_chunks && e == hipSuccess && rc == MZ_OK; ++c) {
-        const int slot = (int)(c & 1);
-        hipStream_t st = p->stream[slot];
-        if (c < n_chunks) {
+    const PipeCopyThreads ct = pipe_copy_threads(n_chunks > 2);
+    rc = run_pipe(p, n_chunks, "k2u_reads",
+        [&](uint64_t c, int slot) -> int {
+            hipStream_t st = p->stream[slot];
             const uint64_t r0 = cut[c], r1 = cut[c + 1], nr = r1 - r0, nb = read_offsets[r1] - read_offsets[r0];
             uint64_t *h_ro = p->h_in[slot], *h_ko = h_ro + (nr + 1);
             uint8_t *h_b = reinterpret_cast<uint8_t *>(h_ko + (nr + 1));
             for (uint64_t i = 0; i <= nr; ++i) { h_ro[i] = read_offsets[r0 + i] - read_offsets[r0]; h_ko[i] = ko[r0 + i] - ko[r0]; }
-            parallel_copy(h_b, bases + read_offsets[r0], nb);
+            parallel_copy(h_b, bases + read_offsets[r0], nb, ct.stage);
             const uint64_t in_bytes = 16 * (nr + 1) + nb, n_win = ko[r1] - ko[r0];
             uint64_t *d_ro = p->d_in[slot], *d_ko = d_ro + (nr + 1);
             const uint8_t *d_b = reinterpret_cast<const uint8_t *>(d_ko + (nr + 1));
-            if ((e = hipMemcpyAsync(p->d_in[slot], p->h_in[slot], in_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-            if ((rc = launch_k2u_reads(*ix->dev, d_b, nb, d_ro, d_ko, nr, streaming, p->d_out[slot], p->d_counts, st)) != MZ_OK) break;
-            if (n_win && (e = hipMemcpyAsync(p->h_out[slot], p->d_out[slot], n_win * sizeof(mz_k2upos), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
-            if (c + 1 == n_chunks) {
-                if (c >= 1 && (e = hipStreamWaitEvent(st, p->done[slot ^ 1], 0)) != hipSuccess) break;
-                if ((e = hipMemcpyAsync(p->h_counts, p->d_counts, sizeof(mz_counts), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+            hipError_t e = hipMemcpyAsync(p->d_in[slot], p->h_in[slot], in_bytes, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) {
+                const int r = launch_k2u_reads(*ix->dev, d_b, nb, d_ro, d_ko, nr, streaming, p->d_out[slot], p->d_counts, st);
+                if (r != MZ_OK) return r;
+                if (n_win) e = hipMemcpyAsync(p->h_out[slot], p->d_out[slot], n_win * sizeof(mz_k2upos), hipMemcpyDeviceToHost, st);
             }
-            if ((e = hipEventRecord(p->done[slot], st)) != hipSuccess) break;
-        }
-        if (c >= 1) {
-            const uint64_t r0 = cut[c - 1], r1 = cut[c], n_win = ko[r1] - ko[r0];
-            if ((e = hipEventSynchronize(p->done[slot ^ 1])) != hipSuccess) break;
-            if (n_win) parallel_copy(out + ko[r0], p->h_out[slot ^ 1], n_win * sizeof(mz_k2upos));
-        }
-    }
-    if (e != hipSuccess) {
-        set_error("HIP error in k2u_reads: %s", hipGetErrorString(e));
-        rc = MZ_EHIP;
-    }
-    if (rc != MZ_OK) { (void)hipStreamSynchronize(p->stream[0]); (void)hipStreamSynchronize(p->stream[1]); }
+            if (e != hipSuccess) { set_error("HIP error in k2u_reads: %s", hipGetErrorString(e)); return MZ_EHIP; }
+            return MZ_OK;
+        },
+        [&](uint64_t c, int slot) {
+            const uint64_t r0 = cut[c], r1 = cut[c + 1], n_win = ko[r1] - ko[r0];
+            if (n_win) parallel_copy(out + ko[r0], p->h_out[slot], n_win * sizeof(mz_k2upos), ct.drain);
+        });
     if (rc == MZ_OK && counts) *counts = *p->h_counts;
     pipe_release(ix, p);
     return rc;
@@ -485,7 +563,7 @@ int mz_sshash_k2u_reads(mz_sshash *ix, const uint8_t *bases, const uint64_t *rea
     std::vector<uint64_t> ro(n_reads + 1);
     for (uint64_t r = 0; r <= n_reads; ++r) ro[r] = read_offsets[r] - base0;
     HIPC(hipSetDevice(ix->dev->device));
-    { // pipelined form (same two-slot staging as mz_sshash_k2u_batch) when every read fits one chunk; else the plain form below
+    { // pipelined form (same staging pipe as mz_sshash_k2u_batch) when every read fits one chunk; else the plain form below
         int prc = k2u_reads_pipelined(ix, bases, read_offsets, ko.data(), n_reads, streaming, out, counts);
         if (prc != MZ_EUNSUPPORTED_INTERNAL) return prc;
     }

@@ -198,19 +198,24 @@ class SSHash:  # sshash.rs:39-51
         check(lib.mz_sshash_k2u(self._h, km.get_fw_mer(), len(km), C.byref(out)))
         return None if out.match == 0 else K2UPos(out.unitig_id, out.unitig_len, out.pos, out.match)
 
-    def k2u_batch(self, fw_words):
+    def k2u_batch(self, fw_words, out=None):
+        """host arrays in, host records out; `out` lets a caller reuse its result buffer (a fresh one costs a page fault per 4 KiB)"""
         fw = np.ascontiguousarray(fw_words, dtype=np.uint64)
-        out = np.zeros(len(fw), dtype=K2UPOS_DTYPE)
+        if out is None:
+            out = np.zeros(len(fw), dtype=K2UPOS_DTYPE)
+        assert out.dtype == K2UPOS_DTYPE and len(out) >= len(fw) and out.flags.c_contiguous
         cnt = _capi.Counts()
         check(lib.mz_sshash_k2u_batch(self._h, fw.ctypes.data, len(fw), out.ctypes.data, C.byref(cnt)))
         return out, (cnt.n_hit, cnt.n_miss, cnt.n_skipped)
 
-    def k2u_reads(self, bases, read_offsets, streaming=False):
+    def k2u_reads(self, bases, read_offsets, streaming=False, out=None):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         ro = np.ascontiguousarray(read_offsets, dtype=np.uint64)
         n_reads = len(ro) - 1
         n_win = lib.mz_reads_n_windows(ro.ctypes.data, n_reads, self.k())
-        out = np.zeros(n_win, dtype=K2UPOS_DTYPE)
+        if out is None:
+            out = np.zeros(n_win, dtype=K2UPOS_DTYPE)
+        assert out.dtype == K2UPOS_DTYPE and len(out) >= n_win and out.flags.c_contiguous
         cnt = _capi.Counts()
         check(lib.mz_sshash_k2u_reads(self._h, bases.ctypes.data, ro.ctypes.data, n_reads, 1 if streaming else 0,
                                       out.ctypes.data, C.byref(cnt)))

@@ -411,7 +411,7 @@ def test_gpu_built_index_is_bit_identical_to_host_built(prefix, w, skew, tmp_pat
 
 
 def test_host_pointer_batch_walks_several_chunks(yeast, monkeypatch):
-    """mz_sshash_k2u_batch pipelines chunks through two pinned slots: odd chunk size, partial last chunk, 1 and 2 chunks"""
+    """mz_sshash_k2u_batch pipelines chunks through its pinned slots (13 and 3 chunks: drained by the helper thread; 2 and 1: by the caller): odd chunk size, partial last chunk"""
     k, seqs = yeast
     ix, orc, (words, total, starts) = both(seqs, k, 15, 16)
     ix.to_device(0)

@@ -15,12 +15,23 @@ ix = M.SSHash.from_unitig_set(M.UnitigSet.from_packed(us["words"].cpu().numpy().
 ix.to_device(0)
 q = synth.make_query_mix(ix, us, n, seed=5, device="cuda").cpu().numpy().view(np.uint64)
 ix.k2u_batch(q[:1_000_000])
-best = 1e9
-for _ in range(3):
-    t0 = time.time()
-    out, counts = ix.k2u_batch(q)
-    best = min(best, time.time() - t0)
-print(f"{wl}: host-pointer k2u_batch of {n} queries: {best*1e3:.1f} ms = {n/best/1e6:.1f} M k-mers/s (PCIe-inclusive, best of 3), hits {counts[0]}")
+for chunk in [None] + [int(c) for c in os.environ.get("CHUNKS", "").split(",") if c]:
+    if chunk:
+        os.environ["MZ_HOST_CHUNK"] = str(chunk)
+        ix.k2u_batch(q[:4 * chunk])  # the pipe's buffers grow outside the timed calls
+    best = 1e9
+    for _ in range(3):
+        t0 = time.time()
+        out, counts = ix.k2u_batch(q)
+        best = min(best, time.time() - t0)
+    print(f"{wl}: chunk {chunk or 'default'}: host-pointer k2u_batch of {n} queries: {best*1e3:.1f} ms = {n/best/1e6:.1f} M k-mers/s (PCIe-inclusive, best of 3, fresh result array per call), hits {counts[0]}", flush=True)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.time()
+        _, counts = ix.k2u_batch(q, out=out)
+        best = min(best, time.time() - t0)
+    print(f"{wl}: chunk {chunk or 'default'}: same into a result array the caller reuses: {best*1e3:.1f} ms = {n/best/1e6:.1f} M k-mers/s", flush=True)
+os.environ.pop("MZ_HOST_CHUNK", None)
 for m in (1, 1000, 100_000):
     t0 = time.time()
     reps = 200
