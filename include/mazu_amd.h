@@ -242,7 +242,9 @@ uint64_t mz_u2pos_noalloc_max_queries(void);
  * records are d_recs: d_report[3] = {k-mers checked, failures, first failing position}, accumulated (init {0,0,~0}) */
 int mz_u2pos_check_refs_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint32_t ref_id, uint64_t *d_report,
                                void *stream);
-/* GetRefPos::get_ref_pos_eager for a batch (index.rs:139-179), host buffers; *n_out = total records (may exceed out_cap) */
+/* GetRefPos::get_ref_pos_eager for a batch (index.rs:139-179), host buffers, walked in chunks through pinned staging slots;
+ * hit_offsets[n + 1] = prefix sums of the records per query, out = the records that fit out_cap (may be NULL to only count),
+ * *n_out = total records (may exceed out_cap); a record's `query` is the index of its k-mer in fw_words */
 int mz_get_ref_pos_batch(mz_sshash *ix, mz_u2pos *u, const uint64_t *fw_words, uint64_t n, uint64_t *hit_offsets,
                          mz_mapped_ref_pos *out, uint64_t out_cap, uint64_t *n_out);
 

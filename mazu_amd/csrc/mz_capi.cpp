@@ -9,6 +9,7 @@
 #include <exception>
 #include <cstdlib>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -267,20 +268,29 @@ static uint64_t host_chunk_queries() {
     long long v = e ? atoll(e) : 0;
     return (uint64_t)(v > 0 ? v : (2ll << 20));
 }
-// copies with a few host threads (one memcpy stream is ~10 GB/s, the PCIe link wants ~50)
-static void parallel_copy(void *dst, const void *src, uint64_t bytes, int max_threads = 8) {
-    const uint64_t kMin = 2ull << 20;
-    int nt = (int)std::min<uint64_t>(std::max(1, std::min<int>(hw_threads(), max_threads)), bytes / kMin);
-    if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+} // extern "C"
+namespace mz {
+// fn(0 .. n_tasks-1), task 0 on the calling thread and the others on threads of their own (a staging copy of a few megabytes
+// lasts a fraction of a millisecond; a pool of kept threads measured no faster than starting them)
+void parallel_for(int n_tasks, const std::function<void(int)> &fn) {
     std::vector<std::thread> th;
-    const uint64_t per = ((bytes + nt - 1) / nt + 4095) & ~4095ull;
-    for (int t = 0; t < nt; ++t) {
-        const uint64_t b = std::min<uint64_t>(bytes, per * t), e = std::min<uint64_t>(bytes, b + per);
-        if (b >= e) break;
-        th.emplace_back([=] { std::memcpy((char *)dst + b, (const char *)src + b, e - b); });
-    }
+    for (int t = 1; t < n_tasks; ++t) th.emplace_back([&fn, t] { fn(t); });
+    if (n_tasks > 0) fn(0);
     for (auto &x : th) x.join();
 }
+// copies with a few host threads (one memcpy stream is ~10 GB/s, the PCIe link wants ~50)
+void parallel_copy(void *dst, const void *src, uint64_t bytes, int max_threads) {
+    const uint64_t kMin = 2ull << 20;
+    const int nt = (int)std::min<uint64_t>(std::max(1, std::min<int>(hw_threads(), max_threads)), bytes / kMin);
+    if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+    const uint64_t per = ((bytes + nt - 1) / nt + 4095) & ~4095ull;
+    parallel_for(nt, [=](int t) {
+        const uint64_t b = std::min<uint64_t>(bytes, per * t), e = std::min<uint64_t>(bytes, b + per);
+        if (b < e) std::memcpy((char *)dst + b, (const char *)src + b, e - b);
+    });
+}
+} // namespace mz
+extern "C" {
 
 static int pipe_acquire(mz_sshash *ix, uint64_t want, HostPipe **out) {
     HostPipe *p = nullptr;

@@ -1,5 +1,6 @@
 // mz_device.hpp -- device replica of an SSHash index and the kernel launchers (gfx950).
 #pragma once
+#include <functional>
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
@@ -58,3 +59,9 @@ int device_download(const DeviceIndex &d, SSHashHost &h);
 
 // device of the replica the host-pointer entry points of `ix` use (placed on device 0 first if the index is not resident yet)
 int mz_internal_default_device(mz_sshash *ix, int *device);
+namespace mz {
+// memcpy split over up to `max_threads` host threads (pageable <-> pinned staging copies of the host-pointer entry points)
+void parallel_copy(void *dst, const void *src, uint64_t bytes, int max_threads = 8);
+// fn(0 .. n_tasks-1) on the library's helper threads and the calling thread; returns when all have run
+void parallel_for(int n_tasks, const std::function<void(int)> &fn);
+} // namespace mz

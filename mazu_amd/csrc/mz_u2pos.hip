@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -24,7 +25,44 @@ struct OccCodec {
 };
 struct DecodedOcc { uint32_t ref_id, pos; bool fwd; };
 
+// Staging of one chunk of mz_get_ref_pos_batch: pinned host buffers and their device twins, a stream, and the scan's tile sums.
+struct RefPosSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t offsets_ready = nullptr;
+    uint64_t *h_q = nullptr, *d_q = nullptr, *h_off = nullptr, *d_off = nullptr, *d_tiles = nullptr;
+    mz_k2upos *d_recs = nullptr;
+    mz_mapped_ref_pos *h_out = nullptr, *d_out = nullptr;
+    uint64_t out_cap = 0; // records h_out / d_out hold
+    uint64_t fit = 0, first_record = 0; // of the chunk in flight: records the caller has room for, and where they go
+    void release_out() {
+        if (h_out) (void)hipHostFree(h_out);
+        if (d_out) (void)hipFree(d_out);
+        h_out = d_out = nullptr; out_cap = 0;
+    }
+    void release() {
+        release_out();
+        if (h_q) (void)hipHostFree(h_q);
+        if (h_off) (void)hipHostFree(h_off);
+        if (d_q) (void)hipFree(d_q);
+        if (d_off) (void)hipFree(d_off);
+        if (d_tiles) (void)hipFree(d_tiles);
+        if (d_recs) (void)hipFree(d_recs);
+        if (offsets_ready) (void)hipEventDestroy(offsets_ready);
+        if (stream) (void)hipStreamDestroy(stream);
+        *this = RefPosSlot{};
+    }
+};
+struct RefPosPipe {
+    int device = -1;
+    uint64_t cap = 0; // queries per chunk
+    static constexpr int kSlots = 3; // chunk c + 2 is staged while the offsets of chunk c + 1 and the records of chunk c come back
+    RefPosSlot slot[kSlots];
+    void release() { for (RefPosSlot &s : slot) s.release(); cap = 0; }
+};
+
 struct mz_u2pos {
+    std::vector<RefPosPipe *> idle_pipes; // guarded by mu; a call of mz_get_ref_pos_batch takes one, concurrent callers get their own
+    std::mutex mu;
     std::vector<uint64_t> ctable, offsets; // host copies: occurrence words (packed for piscem, + 2 pad words) and plain unitig offsets
     uint64_t n_unitigs = 0, n_occs = 0;
     uint32_t width = 64, ref_shift = 0, piscem = 0;
@@ -141,7 +179,7 @@ __global__ __launch_bounds__(kB) void scan_apply(uint64_t *__restrict__ counts, 
 // fill: one lane per query for short lists; a query with >= 64 occurrences is walked by its whole wave
 __global__ __launch_bounds__(kB) void fill_kernel(const mz_k2upos *__restrict__ recs, uint64_t n, const uint64_t *__restrict__ table_off,
                                                   OccCodec ctable, const uint64_t *__restrict__ out_off, uint32_t k,
-                                                  mz_mapped_ref_pos *__restrict__ out, uint64_t cap) {
+                                                  mz_mapped_ref_pos *__restrict__ out, uint64_t cap, uint64_t query_base) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
     uint64_t n_round = (n + 63) & ~63ull;
     for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n_round; i += stride) {
@@ -156,7 +194,7 @@ __global__ __launch_bounds__(kB) void fill_kernel(const mz_k2upos *__restrict__ 
         const bool longl = c >= 64;
         if (c && !longl)
             for (uint64_t j = 0; j < c; ++j)
-                if (o0 + j < cap) out[o0 + j] = project(r, decode_occ(ctable, t0 + j), k, i);
+                if (o0 + j < cap) out[o0 + j] = project(r, decode_occ(ctable, t0 + j), k, query_base + i);
         unsigned long long lb = __ballot(longl);
         while (lb) { // wave-cooperative walk of the long lists of this wave's 64 queries
             int src = __ffsll((long long)lb) - 1;
@@ -166,7 +204,7 @@ __global__ __launch_bounds__(kB) void fill_kernel(const mz_k2upos *__restrict__ 
             rr.unitig_len = __shfl(r.unitig_len, src); rr.match = __shfl(r.match, src);
             uint64_t so = __shfl(o0, src), sc = __shfl(c, src), st = __shfl(t0, src), sq = __shfl(i, src);
             for (uint64_t j = __lane_id(); j < sc; j += 64)
-                if (so + j < cap) out[so + j] = project(rr, decode_occ(ctable, st + j), k, sq);
+                if (so + j < cap) out[so + j] = project(rr, decode_occ(ctable, st + j), k, query_base + sq);
         }
     }
 }
@@ -224,15 +262,16 @@ int resolve_scratch(int device) {
 __global__ void zero_word_kernel(uint64_t *p) { *p = 0; }
 
 // count -> exclusive scan -> fill on `stream`, tile sums in d_tiles (n_tiles + 2 words); shared by both entry points
+// (`query_base` is added to the query index a record carries: a caller that walks a batch in chunks passes the chunk's first query)
 void launch_project(const mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets, mz_mapped_ref_pos *d_out, uint64_t out_cap,
-                    uint64_t *d_tiles, hipStream_t stream) {
+                    uint64_t *d_tiles, hipStream_t stream, uint64_t query_base = 0) {
     const uint64_t n_tiles = (n + kTileN - 1) / kTileN;
     hipLaunchKernelGGL(count_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->n_unitigs, d_offsets);
     hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)n_tiles), dim3(kB), 0, stream, d_offsets, n, d_tiles);
     hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(kB), 0, stream, d_tiles, n_tiles, d_tiles + n_tiles);
     hipLaunchKernelGGL(scan_apply, dim3((unsigned)n_tiles), dim3(kB), 0, stream, d_offsets, n, d_tiles, d_tiles + n_tiles);
     if (d_out && out_cap)
-        hipLaunchKernelGGL(fill_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->codec(), d_offsets, k, d_out, out_cap);
+        hipLaunchKernelGGL(fill_kernel, dim3(grid_of(n)), dim3(kB), 0, stream, d_recs, n, u->d_offsets, u->codec(), d_offsets, k, d_out, out_cap, query_base);
 }
 
 int ensure_u2pos_device(mz_u2pos *u, int device) {
@@ -315,6 +354,7 @@ void mz_u2pos_free(mz_u2pos *u) {
     if (!u) return;
     DeviceGuard guard;
     if (u->d_ctable) { (void)hipSetDevice(u->device); (void)hipFree(u->d_ctable); (void)hipFree(u->d_offsets); }
+    for (RefPosPipe *p : u->idle_pipes) { (void)hipSetDevice(p->device); p->release(); delete p; }
     delete u;
 }
 uint64_t mz_u2pos_n_unitig_occs(const mz_u2pos *u, uint64_t ui) { return ui < u->n_unitigs ? u->offsets[ui + 1] - u->offsets[ui] : 0; }
@@ -386,41 +426,153 @@ int mz_u2pos_check_refs_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs,
     return MZ_OK;
 }
 
-// GetRefPos::get_ref_pos_eager for a batch (src/index.rs:139-179), host buffers: k2u on the GPU, projection on the GPU
+// GetRefPos::get_ref_pos_eager for a batch (src/index.rs:139-179), host buffers: k2u on the GPU, projection on the GPU.
+// The batch is walked in chunks through three staging slots (pinned buffers, one stream each).  The number of records of a chunk
+// is known only when its offsets are back on the host, so a chunk passes three steps, one per iteration of the host loop and
+// each overlapping the other two of its neighbours: (1) upload, lookup, count + scan + fill, offsets back; (2) offsets rebased
+// into the caller's array, records requested; (3) records copied to the caller.  A slot's record buffer starts at two records
+// per query and grows to what a chunk needs (the fill is then repeated: the offsets stand).
+static uint64_t refpos_chunk_queries() {
+    const char *e = std::getenv("MZ_REFPOS_CHUNK"); // read per call: tests shrink it to walk the multi-chunk path
+    const long long v = e ? atoll(e) : 0;
+    return (uint64_t)(v > 0 ? v : (1ll << 20));
+}
+static int refpos_grow_out(RefPosSlot &s, uint64_t want) {
+    if (s.out_cap >= want) return MZ_OK;
+    uint64_t r = 4096;
+    while (r < want) r <<= 1;
+    s.release_out();
+    hipError_t e;
+    if ((e = hipHostMalloc((void **)&s.h_out, r * sizeof(mz_mapped_ref_pos), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipMalloc((void **)&s.d_out, r * sizeof(mz_mapped_ref_pos))) != hipSuccess) {
+        s.release_out();
+        (void)hipGetLastError();
+        set_error("record buffers for %llu MappedRefPos records: %s", (unsigned long long)r, hipGetErrorString(e));
+        return MZ_ENOMEM;
+    }
+    s.out_cap = r;
+    return MZ_OK;
+}
+static int refpos_pipe_acquire(mz_u2pos *u, int device, uint64_t want, RefPosPipe **out) {
+    RefPosPipe *p = nullptr;
+    {
+        std::lock_guard<std::mutex> g(u->mu);
+        for (size_t j = 0; j < u->idle_pipes.size(); ++j)
+            if (u->idle_pipes[j]->device == device) { p = u->idle_pipes[j]; u->idle_pipes.erase(u->idle_pipes.begin() + j); break; }
+    }
+    if (!p) { p = new RefPosPipe; p->device = device; }
+    if (p->cap < want) {
+        uint64_t r = 4096;
+        while (r < want) r <<= 1;
+        p->release();
+        hipError_t e = hipSuccess;
+        bool ok = true;
+        for (int j = 0; j < RefPosPipe::kSlots && ok; ++j) {
+            RefPosSlot &s = p->slot[j];
+            ok = (e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) == hipSuccess &&
+                 (e = hipEventCreateWithFlags(&s.offsets_ready, hipEventDisableTiming)) == hipSuccess &&
+                 (e = hipHostMalloc((void **)&s.h_q, r * 8, hipHostMallocDefault)) == hipSuccess &&
+                 (e = hipHostMalloc((void **)&s.h_off, (r + 1) * 8, hipHostMallocDefault)) == hipSuccess &&
+                 (e = hipMalloc((void **)&s.d_q, r * 8)) == hipSuccess && (e = hipMalloc((void **)&s.d_off, (r + 1) * 8)) == hipSuccess &&
+                 (e = hipMalloc((void **)&s.d_tiles, ((r + kTileN - 1) / kTileN + 2) * 8)) == hipSuccess &&
+                 (e = hipMalloc((void **)&s.d_recs, r * sizeof(mz_k2upos))) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            set_error("staging buffers for %llu queries: %s", (unsigned long long)r, hipGetErrorString(e));
+            p->release();
+            delete p;
+            return MZ_ENOMEM;
+        }
+        p->cap = r;
+    }
+    *out = p;
+    return MZ_OK;
+}
 int mz_get_ref_pos_batch(mz_sshash *ix, mz_u2pos *u, const uint64_t *fw_words, uint64_t n, uint64_t *hit_offsets, mz_mapped_ref_pos *out,
                          uint64_t out_cap, uint64_t *n_out) {
     if (!ix || !u || !hit_offsets || !n_out || (n && !fw_words)) { set_error("null argument"); return MZ_EINVAL; }
     *n_out = 0;
+    hit_offsets[0] = 0;
+    if (n == 0) return MZ_OK;
+    if (!out) out_cap = 0;
     DeviceGuard guard;
     int device = 0; // the replica the handle's host-pointer entry points use; the handle is not retargeted
     int rc = mz_internal_default_device(ix, &device);
     if (rc != MZ_OK) return rc;
-    const uint32_t k = mz_sshash_k(ix);
-    uint64_t *d_q = nullptr, *d_off = nullptr;
-    mz_k2upos *d_r = nullptr;
-    mz_mapped_ref_pos *d_o = nullptr;
+    if ((rc = ensure_u2pos_device(u, device)) != MZ_OK) return rc;
     U2_HIP(hipSetDevice(device));
-    auto cleanup = [&] { if (d_q) (void)hipFree(d_q); if (d_off) (void)hipFree(d_off); if (d_r) (void)hipFree(d_r); if (d_o) (void)hipFree(d_o); };
-    hipError_t e;
-    if ((e = hipMalloc((void **)&d_q, std::max<uint64_t>(n, 1) * 8)) != hipSuccess || (e = hipMalloc((void **)&d_off, (n + 1) * 8)) != hipSuccess ||
-        (e = hipMalloc((void **)&d_r, std::max<uint64_t>(n, 1) * sizeof(mz_k2upos))) != hipSuccess ||
-        (e = hipMalloc((void **)&d_o, std::max<uint64_t>(out_cap, 1) * sizeof(mz_mapped_ref_pos))) != hipSuccess) {
-        cleanup();
-        set_error("hipMalloc failed: %s", hipGetErrorString(e));
-        return MZ_ENOMEM;
-    }
-    rc = MZ_OK;
-    if (n && (e = hipMemcpy(d_q, fw_words, n * 8, hipMemcpyHostToDevice)) != hipSuccess) rc = MZ_EHIP;
-    if (rc == MZ_OK) rc = mz_sshash_k2u_batch_device(ix, d_q, n, d_r, nullptr, nullptr);
-    if (rc == MZ_OK) rc = mz_u2pos_project_device(u, k, d_r, n, d_off, out ? d_o : nullptr, out ? out_cap : 0, nullptr);
-    if (rc == MZ_OK && (e = hipMemcpy(hit_offsets, d_off, (n + 1) * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = MZ_EHIP;
-    if (rc == MZ_OK) {
-        *n_out = hit_offsets[n];
-        uint64_t m = std::min(*n_out, out_cap);
-        if (out && m && (e = hipMemcpy(out, d_o, m * sizeof(mz_mapped_ref_pos), hipMemcpyDeviceToHost)) != hipSuccess) rc = MZ_EHIP;
+    const uint32_t k = mz_sshash_k(ix);
+    const uint64_t chunk = std::min<uint64_t>(n, refpos_chunk_queries()), n_chunks = (n + chunk - 1) / chunk;
+    RefPosPipe *p = nullptr;
+    if ((rc = refpos_pipe_acquire(u, device, chunk, &p)) != MZ_OK) return rc;
+    auto span = [&](uint64_t c, uint64_t &b, uint64_t &len) { b = c * chunk; len = std::min<uint64_t>(chunk, n - b); };
+    hipError_t e = hipSuccess;
+    // upload, lookup, count + scan + fill, offsets back: all on the slot's stream
+    auto stage = [&](uint64_t c) -> int {
+        RefPosSlot &s = p->slot[c % RefPosPipe::kSlots];
+        uint64_t b, len;
+        span(c, b, len);
+        if (out_cap) { const int r = refpos_grow_out(s, 2 * len); if (r != MZ_OK) return r; }
+        parallel_copy(s.h_q, fw_words + b, len * 8, 8);
+        if ((e = hipMemcpyAsync(s.d_q, s.h_q, len * 8, hipMemcpyHostToDevice, s.stream)) != hipSuccess) return MZ_EHIP;
+        const int r = mz_sshash_k2u_batch_device(ix, s.d_q, len, s.d_recs, nullptr, s.stream);
+        if (r != MZ_OK) return r;
+        launch_project(u, k, s.d_recs, len, s.d_off, out_cap ? s.d_out : nullptr, out_cap ? s.out_cap : 0, s.d_tiles, s.stream, b);
+        if ((e = hipGetLastError()) != hipSuccess) return MZ_EHIP;
+        if ((e = hipMemcpyAsync(s.h_off, s.d_off, (len + 1) * 8, hipMemcpyDeviceToHost, s.stream)) != hipSuccess) return MZ_EHIP;
+        if ((e = hipEventRecord(s.offsets_ready, s.stream)) != hipSuccess) return MZ_EHIP;
+        return MZ_OK;
+    };
+    uint64_t total = 0; // records of the chunks whose offsets have been taken
+    auto take_offsets = [&](uint64_t c) -> int {
+        RefPosSlot &s = p->slot[c % RefPosPipe::kSlots];
+        uint64_t b, len;
+        span(c, b, len);
+        if ((e = hipEventSynchronize(s.offsets_ready)) != hipSuccess) return MZ_EHIP;
+        const uint64_t n_rec = s.h_off[len];
+        s.first_record = total;
+        s.fit = total < out_cap ? std::min<uint64_t>(n_rec, out_cap - total) : 0; // records of this chunk the caller has room for
+        if (s.fit) {
+            if (s.fit > s.out_cap) { // more occurrences than the slot was sized for: larger buffers, the fill again
+                const int r = refpos_grow_out(s, s.fit);
+                if (r != MZ_OK) return r;
+                hipLaunchKernelGGL(fill_kernel, dim3(grid_of(len)), dim3(kB), 0, s.stream, s.d_recs, len, u->d_offsets, u->codec(), s.d_off, k, s.d_out, s.out_cap, b);
+                if ((e = hipGetLastError()) != hipSuccess) return MZ_EHIP;
+            }
+            if ((e = hipMemcpyAsync(s.h_out, s.d_out, s.fit * sizeof(mz_mapped_ref_pos), hipMemcpyDeviceToHost, s.stream)) != hipSuccess) return MZ_EHIP;
+        }
+        {   // the chunk's offsets rebased onto the batch, while the records travel
+            const uint64_t *src = s.h_off + 1, base = total;
+            uint64_t *dst = hit_offsets + b + 1;
+            const int nt = (int)std::min<uint64_t>(std::max(1, std::min(hw_threads(), 8)), len >> 17);
+            auto rebase = [=](uint64_t i0, uint64_t i1) { for (uint64_t i = i0; i < i1; ++i) dst[i] = base + src[i]; };
+            const uint64_t per = (len + nt - 1) / std::max(nt, 1);
+            if (nt <= 1) rebase(0, len);
+            else parallel_for(nt, [=](int t) { rebase(std::min<uint64_t>(len, per * t), std::min<uint64_t>(len, per * (t + 1))); });
+        }
+        total += n_rec;
+        return MZ_OK;
+    };
+    auto take_records = [&](uint64_t c) -> int {
+        RefPosSlot &s = p->slot[c % RefPosPipe::kSlots];
+        if (!s.fit) return MZ_OK;
+        if ((e = hipStreamSynchronize(s.stream)) != hipSuccess) return MZ_EHIP;
+        parallel_copy(out + s.first_record, s.h_out, s.fit * sizeof(mz_mapped_ref_pos), 8);
+        return MZ_OK;
+    };
+    for (uint64_t i = 0; i < n_chunks + 2 && rc == MZ_OK; ++i) {
+        if (i < n_chunks) rc = stage(i); // its slot was emptied by take_records(i - 3), one iteration ago
+        if (rc == MZ_OK && i >= 1 && i - 1 < n_chunks) rc = take_offsets(i - 1);
+        if (rc == MZ_OK && i >= 2) rc = take_records(i - 2);
     }
     if (rc == MZ_EHIP && e != hipSuccess) set_error("HIP error in get_ref_pos_batch: %s", hipGetErrorString(e));
-    cleanup();
+    if (rc != MZ_OK) { for (RefPosSlot &s : p->slot) (void)hipStreamSynchronize(s.stream); (void)hipGetLastError(); }
+    else *n_out = total;
+    {
+        std::lock_guard<std::mutex> g(u->mu);
+        u->idle_pipes.push_back(p);
+    }
     return rc;
 }
 

@@ -117,7 +117,7 @@ def test_streaming_validate_fasta_piscem_style():  # caching.rs:238-253 / piscem
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,w,skew", [("tiny-multi-refs/tiny-multi-refs_index", 3, 0), ("small_txome_index", 15, 32), ("yeast_chr01_index", 15, 32)])
-def test_projection_on_device_matches_host_projection(name, w, skew):  # index.rs:184-216, dense_unitig_table.rs:55-76
+def test_projection_on_device_matches_host_projection(name, w, skew, monkeypatch):  # index.rs:184-216, dense_unitig_table.rs:55-76
     idx, f = I.dense_index_from_pf1(os.path.join(PF1, name), gpu_factory(w, skew))
     n_dev = idx.validate_self_on_device()               # lookup + projection + assertion on the GPU
     assert n_dev == idx.validate_self()                 # host projection of the same GPU lookups
@@ -138,6 +138,21 @@ def test_projection_on_device_matches_host_projection(name, w, skew):  # index.r
         assert [(int(g["ref_id"]), int(g["pos"]), int(g["o"])) for g in got] == [(m.ref_id, m.pos, m.o) for m in want]
         assert (got["query"] == i).all()
     assert idx.u2pos.num_total_occs() == len(f.ctable)
+    # the batch walked in chunks through the staging slots (odd sizes, a partial last chunk, record buffers that have to grow,
+    # a caller's array that ends inside a chunk): same offsets, same records, query indices of the whole batch
+    for chunk, cap in (("1000", None), ("77", 8), ("4096", len(recs) // 2 + 1)):
+        monkeypatch.setenv("MZ_REFPOS_CHUNK", chunk)
+        if cap is None or cap == 8:
+            o2, r2 = idx.get_ref_pos_batch(fw, cap=cap)
+            assert o2.tobytes() == offs.tobytes() and r2.tobytes() == recs.tobytes(), chunk
+        else:  # one call into an array that is too small: the records that fit are there, the total is reported
+            import ctypes as C
+            from mazu_amd._capi import check, lib
+            o2 = np.zeros(len(fw) + 1, dtype=np.uint64)
+            r2 = np.zeros(cap, dtype=I.MAPPED_DTYPE)
+            n_out = C.c_uint64(0)
+            check(lib.mz_get_ref_pos_batch(idx.k2u._h, idx.u2pos.handle(), fw.ctypes.data, len(fw), o2.ctypes.data, r2.ctypes.data, cap, C.byref(n_out)))
+            assert n_out.value == len(recs) and o2.tobytes() == offs.tobytes() and r2.tobytes() == recs[:cap].tobytes()
 
 
 def test_spt_tiny_known_answers():  # src/spt.rs:156-211
