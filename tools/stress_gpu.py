@@ -9,7 +9,7 @@ import helpers as H
 import mazu_amd as M
 from oracle import oracle as O
 
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "12345")))
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 bad = 0
 for c in range(n_cfg):

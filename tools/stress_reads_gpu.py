@@ -11,7 +11,7 @@ import helpers as H
 import mazu_amd as M
 from oracle import oracle as O
 
-rng = np.random.default_rng(4242)
+rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "4242")))
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 plant = "--no-plant" not in sys.argv  # without the repeat family the sets have no duplicate k-mers: every window is compared bit for bit
 letters = np.frombuffer(b"ACGT", dtype=np.uint8)
