@@ -169,6 +169,9 @@ struct TileLdsT {
     uint32_t qinfo[NT * kQpt];            // expected flank16 of the query | minimizer offset inside g* << 16 | kQMulti
     ListT list_a[NT * kQpt], list_b[NT * kQpt];
     uint32_t cnt_a, cnt_b, cnt_skew, wave_tot[NT / 64];
+#ifdef MZ_DEBUG_COUNT
+    uint32_t dbg[4]; // scratch builds only (tools/ab_build.sh -DMZ_DEBUG_COUNT=n): S3 entries, S5 candidates, exact walks, runs of the tile
+#endif
 #ifdef MZ_LDS_PAD
     uint64_t pad[MZ_LDS_PAD * NT / 64];
 #endif
@@ -488,6 +491,9 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
             n_runs += (uint32_t)__popcll(lead_b);
         }
         SC::sync();
+#ifdef MZ_DEBUG_COUNT
+        if (t == 0) S.dbg[3] = n_runs;
+#endif
         if (ix.front.lines != nullptr) {
             // leaders through the minimizer lines: eight lanes fetch the leader's line (one coalesced 16-byte load each) and find
             // the slots of its key -- they are contiguous, in bucket order.  The run's "bucket" is then that stretch of the line
@@ -726,6 +732,9 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
         if (t == SC::NT - 1) S.eoff[(SC::NT * kQpt)] = excl + sum;
         SC::sync();
         const uint32_t E = S.eoff[(SC::NT * kQpt)];
+#ifdef MZ_DEBUG_COUNT
+        if (t == 0) S.dbg[0] = E;
+#endif
         const uint64_t last_km_start = ix.total_len - k;
         constexpr int kEpt = 4;                    // entries per lane and chunk, their `pos` gathers in flight together
         constexpr uint32_t kChunk = SC::NT * kEpt; // == items per tile, so list_a can hold the marks
@@ -850,6 +859,10 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     SC::sync();
     {
         const uint32_t nc = S.cnt_a;
+#ifdef MZ_DEBUG_COUNT
+        if (t == 0) { S.dbg[1] = nc; S.dbg[2] = 0; }
+        SC::sync();
+#endif
 #ifndef MZ_CPT
 #define MZ_CPT 2
 #endif
@@ -877,7 +890,12 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 const UnitigSpan sp = locate_boundary(bd[a], cp[a]);
                 mz_k2upos r = make_none();
                 if (mt != MZ_NO_MATCH && cp[a] + k <= sp.end) r = make_hit(sp, cp[a], mt);
-                else if (S.qinfo[i] & kQMulti) r = lookup(ix, fw); // more than one survivor and the first one failed: exact in-order rescan
+                else if (S.qinfo[i] & kQMulti) {
+                    r = lookup(ix, fw); // more than one survivor and the first one failed: exact in-order rescan
+#ifdef MZ_DEBUG_COUNT
+                    atomicAdd(&S.dbg[2], 1u);
+#endif
+                }
                 if (r.match != MZ_NO_MATCH) {
                     S.slot[i] = ((uint64_t)r.unitig_id << 32) | r.unitig_len;
                     S.n[i] = r.pos;
@@ -1534,6 +1552,9 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
             tally.add(false, false, state[q] == 1);
         }
         tile_resolve<SC, true>(S, ix);
+#ifdef MZ_DEBUG_COUNT
+        tally.skipped += S.dbg[MZ_DEBUG_COUNT - 1];
+#endif
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             const bool pend = state[q] == 2;
