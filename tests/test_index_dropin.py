@@ -223,3 +223,37 @@ def test_piscem_index_validate_fasta_and_projection_parity(name, w, skew):  # pi
     po, pr = pidx.get_ref_pos_batch(fw)
     do, dr = didx.get_ref_pos_batch(fw)
     assert po.tobytes() == do.tobytes() and pr.tobytes() == dr.tobytes() and len(pr) > 5_000
+
+
+@pytest.mark.gpu
+def test_get_ref_pos_batch_grows_its_record_buffers(monkeypatch):
+    """unitigs with 40 occurrences each: a chunk's records outgrow the two-per-query buffers its staging slot starts with, so the slot
+    grows and the fill is repeated; chunked and unchunked calls agree, every query has 40 records or none, and sampled records equal
+    the host projection (index.rs:184-216)"""
+    k, seqs = H.load_cf_seqs(os.path.join(H.GOLDEN, "cf", "yeast_chr7", "yeast_chr7"))
+    words, total, starts = H.pack_seqs(seqs)
+    n_u, per = len(seqs), 40
+    j = np.tile(np.arange(per, dtype=np.uint64), n_u)
+    u = np.repeat(np.arange(n_u, dtype=np.uint64), per)
+    fwd = (u + j) & np.uint64(1)
+    ctable = (fwd << np.uint64(63)) | ((np.uint64(5000) * j + u) << np.uint64(32)) | j   # [63] forward, [62:32] position, [31:0] reference
+    table = I.DenseUnitigTable(ctable, np.arange(n_u + 1, dtype=np.uint64) * np.uint64(per), [f"r{r}" for r in range(per)])
+    k2u = M.SSHash.from_unitig_set(M.UnitigSet.from_packed(words, total, starts, k), 15, 16)
+    idx = I.ModIndex.from_parts(None, k2u, table, None)
+    fw = H.query_mix(words, starts, k, 6000, seed=21)
+    recs_k2u, _ = k2u.k2u_batch(fw)
+    n_hit = int((recs_k2u["match"] != 0).sum())
+    offs, recs = idx.get_ref_pos_batch(fw)                       # one chunk: 6 000 queries, ~120 000 records against room for 16 384
+    assert int(offs[-1]) == len(recs) == per * n_hit and n_hit > 2000
+    assert set(np.diff(offs.astype(np.int64)).tolist()) == {0, per}
+    for chunk in ("1000", "4097"):
+        monkeypatch.setenv("MZ_REFPOS_CHUNK", chunk)             # ~20 000 records per chunk against room for 4 096
+        o2, r2 = idx.get_ref_pos_batch(fw)
+        assert o2.tobytes() == offs.tobytes() and r2.tobytes() == recs.tobytes(), chunk
+    rng = np.random.default_rng(2)
+    for i in rng.choice(np.flatnonzero(recs_k2u["match"] != 0), 50, replace=False):
+        got = recs[int(offs[i]): int(offs[i + 1])]
+        ref_id, cpos, f = I.DenseUnitigTable.decode_pf1(table.encoded_unitig_occs(int(recs_k2u[i]["unitig_id"])))
+        want = I.project_onto_u_occs(k, recs_k2u[i], ref_id, cpos, f)
+        assert [(int(g["ref_id"]), int(g["pos"]), int(g["o"])) for g in got] == [(m.ref_id, m.pos, m.o) for m in want]
+        assert (got["query"] == i).all()
