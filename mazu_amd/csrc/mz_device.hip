@@ -1385,6 +1385,7 @@ __device__ __forceinline__ uint64_t packed_mer(const uint64_t *packed, uint32_t 
     const uint64_t lo = packed[wi], hi = packed[wi + 1];
     return ((lo >> sh) | ((hi << 1) << (63 - sh))) & kmer_mask(len);
 }
+template <bool kPerItemLines> // true: every window scans its minimizer line itself (stage SF), as a point query does; false: one lookup per run of windows
 __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
                                                                               const uint64_t *__restrict__ read_offsets,
                                                                               const uint64_t *__restrict__ kmer_offsets, uint64_t n_reads,
@@ -1512,8 +1513,7 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
         uint32_t state[kQpt]; // 0 = no window here, 1 = window with a non-ACGT byte, 2 = valid k-mer (answer pending)
         const bool slow = R.slow != 0;
         uint64_t r = R.read0;
-#pragma unroll
-        for (int q = 0; q < kQpt; ++q) {
+        auto s0_row = [&](int q) {
             const uint32_t i = q * 64 + lane; // item == position inside the tile
             const uint64_t b = B0 + i;
             state[q] = 0;
@@ -1543,15 +1543,24 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
                 mn.offset = fw <= rc ? low - i : (k - w) - ((1u << kTilePosBits) - 1 - low - i);
                 mn.word = ((fw <= rc ? fw : rc) >> (2 * mn.offset)) & kmer_mask(w);
             }
-            tile_set_query<SC>(S, i, fw, rc, mn, k, w, query, false); // (runs are resolved per leader: no per-item line pattern)
+            tile_set_query<SC>(S, i, fw, rc, mn, k, w, query, kPerItemLines); // (runs are resolved per leader: no per-item line pattern)
             if (state[q] == 1) { // non-ACGT window: reported, never queried
                 mz_k2upos sk = make_none();
                 sk.match = MZ_SKIPPED;
                 out[out_idx[q]] = sk;
             }
             tally.add(false, false, state[q] == 1);
+        };
+#ifndef MZ_READS_ROW_S0
+#define MZ_READS_ROW_S0 0 // 1: per-item form with the rows of the tile prepared inside stage SF, one batch of lines ahead, as the point kernel does (44 bytes of scratch per lane here: 21.4 against 23.5 G windows/s on S-human)
+#endif
+        if constexpr (kPerItemLines && MZ_READS_ROW_S0) {
+            tile_resolve<SC, false>(S, ix, s0_row);
+        } else {
+#pragma unroll
+            for (int q = 0; q < kQpt; ++q) s0_row(q);
+            tile_resolve<SC, !kPerItemLines>(S, ix);
         }
-        tile_resolve<SC, true>(S, ix);
 #ifdef MZ_DEBUG_COUNT
         tally.skipped += S.dbg[MZ_DEBUG_COUNT - 1];
 #endif
@@ -1841,10 +1850,13 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
     MZ_HIP_CHECK(hipSetDevice(d.device));
     const dim3 grid(tile_grid(d, (n_bases + kTileQ - 1) / kTileQ, 8));
     (void)streaming; // same kernel: see the note above k2u_reads_kernel
-    // The windows of a read share their minimizer for ~9 positions.  Through the minimizer records one lookup serves a whole
-    // run of windows; through the minimizer lines every window fetches its line (mostly from the caches).  Measured: the
-    // records win while records + entries stay cache-friendly (s-txome, 60 M entries: 22.8 against 20.5 G windows/s), the
-    // lines win on large indexes (S-human, 547 M entries: 16.2 against 15.2).  MZ_READS_LINES=0/1 overrides the rule.
+    // The windows of a read share their minimizer for ~9 positions, and the windows of one strand class form runs of ~4.6.
+    // Small indexes: one lookup per run through the minimizer records, the run's bucket then scanned by each of its windows
+    // (stage S3).  Large indexes (2^28 bucket entries and more): through the minimizer lines, and there every window scans
+    // its line itself as a point query does (stage SF: the flank test of all 16 slots costs a window less than S3 costs it
+    // when buckets hold several entries, 4.5 per window on the GRCh38-shaped set; the line comes from the caches for all
+    // but the first window of a run).  Measured in G windows/s, run / item: s-txome (60 M entries, lines forced) 31.2 / 28.5,
+    // records 32.1; S-human (547 M) 21.2 / 23.4; s-pan (1.2 G) 15.9 / 19.3.  MZ_READS_LINES=0/1 and MZ_READS_RESOLVE=run/item override.
     IndexView v = d.view;
     const char *lines_env = getenv("MZ_READS_LINES");
     const bool use_lines = lines_env ? lines_env[0] != '0' : d.n_entries >= (1ull << 28);
@@ -1856,7 +1868,11 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
         // 2.67 rounds --, 24: 31.7, 96: 30.7 G windows/s on s-txome; every wave starts with a search for its first read)
         const char *ge = getenv("MZ_READS_GRID");
         const dim3 wgrid(tile_grid(d, (n_wave_tiles + kBlock / 64 - 1) / (kBlock / 64), ge && atoi(ge) > 0 ? (unsigned)atoi(ge) : 24u));
-        hipLaunchKernelGGL(k2u_reads_wave_kernel, wgrid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
+        const char *rr = getenv("MZ_READS_RESOLVE");
+        if (v.front.lines != nullptr && !(rr && rr[0] == 'r'))
+            hipLaunchKernelGGL(k2u_reads_wave_kernel<true>, wgrid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
+        else
+            hipLaunchKernelGGL(k2u_reads_wave_kernel<false>, wgrid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
     } else if (v.k == 31 && v.w == 15)
         hipLaunchKernelGGL(k2u_reads_kernel<kKW3115>, grid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
                            n_reads, d_out, d_counts);

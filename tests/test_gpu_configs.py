@@ -72,8 +72,8 @@ def test_s_eighth_headline_kernel_matches_oracle(monkeypatch, front):
     assert abs(n_hit - 1_200_000) <= 8  # positives hit; NEG-U / NEG-1 negatives miss (up to accidental members)
 
 
-@pytest.mark.parametrize("bytes_per_key,kind,reads_lines", [("48", 1, None), ("48", 1, "1"), ("16", 0, None)])
-def test_s_txome_reads_match_oracle_streaming_walk(monkeypatch, bytes_per_key, kind, reads_lines):
+@pytest.mark.parametrize("bytes_per_key,kind,reads_lines,resolve", [("48", 1, None, None), ("48", 1, "1", "run"), ("48", 1, "1", "item"), ("16", 0, None, None)])
+def test_s_txome_reads_match_oracle_streaming_walk(monkeypatch, bytes_per_key, kind, reads_lines, resolve):
     """BASELINE configs[2] shape: 150-bp reads over a 145 Mbp, 1.2 M-unitig set, requested as .as_streaming();
     every window must equal the oracle's StreamingK2U walk (index/caching.rs:65-103, bin/kphf/main.rs:299-312).
     Once with the direct-address minimizer records the size rule picks for this set (the reads kernel then resolves one
@@ -84,6 +84,8 @@ def test_s_txome_reads_match_oracle_streaming_walk(monkeypatch, bytes_per_key, k
     monkeypatch.setenv("MZ_DIRECT_BYTES_PER_KEY", bytes_per_key)
     if reads_lines is not None:
         monkeypatch.setenv("MZ_READS_LINES", reads_lines)
+    if resolve is not None:  # through the lines: one lookup per run of windows, or every window scanning its line (the default on large indexes)
+        monkeypatch.setenv("MZ_READS_RESOLVE", resolve)
     us = synth.make_unitig_set("s-txome", device="cuda")
     ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
     assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and ix.minimizer_mphf_kind() == kind

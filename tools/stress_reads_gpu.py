@@ -24,11 +24,14 @@ for c in range(n_cfg):
     os.environ.pop("MZ_DIRECT_BYTES_PER_KEY", None)
     os.environ.pop("MZ_READS_LINES", None)
     os.environ.pop("MZ_FRONT_TABLE", None)
-    mode = int(rng.integers(0, 4))
+    os.environ.pop("MZ_READS_RESOLVE", None)
+    mode = int(rng.integers(0, 5))
     if w == 15 and mode >= 1:
         os.environ["MZ_DIRECT_BYTES_PER_KEY"] = "100000"
         os.environ["MZ_FRONT_TABLE"] = "1"
         os.environ["MZ_READS_LINES"] = "1" if mode >= 2 else "0"
+        if mode >= 2:  # through the lines: per run of windows (2, 3) or every window for itself (4)
+            os.environ["MZ_READS_RESOLVE"] = "item" if mode == 4 else "run"
     codes, starts = H.random_unitigs(seed, int(rng.integers(100, 1200)), float(rng.choice([60, 200, 800])), k, max_len=4000)
     total = int(starts[-1])
     motif = rng.integers(0, 4, int(rng.integers(k + 5, 120)), dtype=np.uint8)
