@@ -26,6 +26,8 @@ for c in range(n_cfg):
     os.environ.pop("MZ_FRONT_TABLE", None)
     os.environ.pop("MZ_READS_RESOLVE", None)
     mode = int(rng.integers(0, 5))
+    if os.environ.get("STRESS_MODE"):  # one form only (e.g. 4: every (31, 15) set through the lines, every window scanning its line)
+        mode = int(os.environ["STRESS_MODE"])
     if w == 15 and mode >= 1:
         os.environ["MZ_DIRECT_BYTES_PER_KEY"] = "100000"
         os.environ["MZ_FRONT_TABLE"] = "1"
