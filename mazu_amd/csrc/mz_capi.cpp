@@ -274,8 +274,14 @@ namespace mz {
 // lasts a fraction of a millisecond; a pool of kept threads measured no faster than starting them)
 void parallel_for(int n_tasks, const std::function<void(int)> &fn) {
     std::vector<std::thread> th;
-    for (int t = 1; t < n_tasks; ++t) th.emplace_back([&fn, t] { fn(t); });
+    int on_threads = 1; // tasks [1, on_threads) got a thread; the others run here (a thread that cannot be started is no error)
+    try {
+        th.reserve(n_tasks > 1 ? n_tasks - 1 : 0);
+        for (int t = 1; t < n_tasks; ++t) { th.emplace_back([&fn, t] { fn(t); }); on_threads = t + 1; }
+    } catch (...) {
+    }
     if (n_tasks > 0) fn(0);
+    for (int t = on_threads; t < n_tasks; ++t) fn(t);
     for (auto &x : th) x.join();
 }
 // copies with a few host threads (one memcpy stream is ~10 GB/s, the PCIe link wants ~50)
@@ -377,11 +383,6 @@ static int run_pipe(HostPipe *p, uint64_t n_chunks, const char *what, Stage stag
     if (e != hipSuccess) {
         set_error("HIP error in %s: %s", what, hipGetErrorString(e));
         rc = MZ_EHIP;
-    } else if (n_chunks <= 2 || hw_threads() < 4) {
-        for (uint64_t c = 0; c <= n_chunks && rc == MZ_OK; ++c) {
-            if (c < n_chunks) rc = put(c);
-            if (rc == MZ_OK && c >= 1) rc = take(c - 1);
-        }
     } else {
         std::mutex m;
         std::condition_variable cv;
@@ -389,7 +390,8 @@ static int run_pipe(HostPipe *p, uint64_t n_chunks, const char *what, Stage stag
         int rc_drain = MZ_OK;
         bool stop = false;
         std::string drain_error;
-        std::thread helper([&] {
+        std::thread helper;
+        auto helper_body = [&] {
             (void)hipSetDevice(p->device);
             for (uint64_t c = 0; c < n_chunks; ++c) {
                 {
@@ -403,8 +405,18 @@ static int run_pipe(HostPipe *p, uint64_t n_chunks, const char *what, Stage stag
                 drained = c + 1;
                 cv.notify_all();
             }
-        });
-        for (uint64_t c = 0; c < n_chunks && rc == MZ_OK; ++c) {
+        };
+        bool threaded = n_chunks > 2 && hw_threads() >= 4;
+        if (threaded) {
+            try { helper = std::thread(helper_body); } catch (...) { threaded = false; } // no thread to be had: the calling thread does both
+        }
+        if (!threaded) {
+            for (uint64_t c = 0; c <= n_chunks && rc == MZ_OK; ++c) {
+                if (c < n_chunks) rc = put(c);
+                if (rc == MZ_OK && c >= 1) rc = take(c - 1);
+            }
+        }
+        for (uint64_t c = 0; threaded && c < n_chunks && rc == MZ_OK; ++c) {
             {
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return drained + kPipeSlots > c || stop; }); // the slot's previous chunk has left it
@@ -415,7 +427,7 @@ static int run_pipe(HostPipe *p, uint64_t n_chunks, const char *what, Stage stag
             if (rc != MZ_OK) stop = true; else staged = c + 1;
             cv.notify_all();
         }
-        helper.join();
+        if (helper.joinable()) helper.join();
         if (rc == MZ_OK && rc_drain != MZ_OK) { rc = rc_drain; set_error("%s", drain_error.c_str()); }
     }
     if (rc != MZ_OK)
