@@ -143,6 +143,33 @@ def _full_size_properties(preset, n_q):
     out_rc, _ = _k2u_device(ix, q_rc)
     rec_rc = out_rc.view(torch.int32).view(-1, 4).to(torch.int64) & 0xFFFFFFFF
     assert torch.equal(rec_rc[:, :3], rec[:, :3]) and torch.equal(rec_rc[:, 3], 3 - rec[:, 3])
+    # reads (at this size every window scans its minimizer line itself): each window must equal the independent lookup of
+    # its k-mer -- the definition of the reads configuration -- through both forms of the reads kernel
+    n_reads, read_len = 100_000, 150
+    bases, ro = synth.make_reads(us, n_reads, read_len, seed=7, device=dev)
+    ko = synth.kmer_offsets(ro, 31)
+    n_win = int(ko[-1])
+    assert n_win == n_reads * (read_len - 30)
+    lut = torch.full((256,), -1, dtype=torch.int64, device=dev)
+    for c, v in zip(b"ACGT", range(4)):
+        lut[c] = v
+    code = lut[bases.to(torch.int64)].view(n_reads, read_len)
+    assert int(code.min()) >= 0  # the generator draws ACGT only
+    fw = torch.zeros((n_reads, read_len - 30), dtype=torch.int64, device=dev)
+    for i in range(31):
+        fw |= code[:, i:i + read_len - 30] << (2 * i)
+    want, (wh, wm, _) = _k2u_device(ix, fw.reshape(-1).contiguous())
+    for resolve in ("item", "run"):
+        os.environ["MZ_READS_RESOLVE"] = resolve
+        try:
+            got = torch.empty(2 * n_win, dtype=torch.int64, device=dev)
+            cnt = torch.zeros(3, dtype=torch.int64, device=dev)
+            ix.k2u_reads_device(bases, ro, ko, got, cnt, streaming=True)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MZ_READS_RESOLVE", None)
+        assert torch.equal(got, want), resolve
+        assert cnt.cpu().tolist() == [wh, wm, 0] and 0.3 < wh / n_win < 0.99
     return ix
 
 
