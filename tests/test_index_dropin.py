@@ -250,6 +250,13 @@ def test_get_ref_pos_batch_grows_its_record_buffers(monkeypatch):
         monkeypatch.setenv("MZ_REFPOS_CHUNK", chunk)             # ~20 000 records per chunk against room for 4 096
         o2, r2 = idx.get_ref_pos_batch(fw)
         assert o2.tobytes() == offs.tobytes() and r2.tobytes() == recs.tobytes(), chunk
+    # counting only (no record array): the offsets and the total, nothing else
+    import ctypes as C
+    from mazu_amd._capi import check, lib
+    o3 = np.zeros(len(fw) + 1, dtype=np.uint64)
+    n_out = C.c_uint64(0)
+    check(lib.mz_get_ref_pos_batch(k2u._h, table.handle(), fw.ctypes.data, len(fw), o3.ctypes.data, None, 0, C.byref(n_out)))
+    assert n_out.value == len(recs) and o3.tobytes() == offs.tobytes()
     rng = np.random.default_rng(2)
     for i in rng.choice(np.flatnonzero(recs_k2u["match"] != 0), 50, replace=False):
         got = recs[int(offs[i]): int(offs[i + 1])]
