@@ -280,6 +280,7 @@ def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
+        D.barrier()  # every rank leaves the group at the same time
         dist.destroy_process_group()
 
 
@@ -409,7 +410,7 @@ def main():
         }
         if validate is not None:
             res["validate_self"] = validate
-        if not args.no_extra_mixes and args.neg_frac == 0.5 and args.neg_kind == "uniform":
+        if n_gpus == 1 and not args.no_extra_mixes and args.neg_frac == 0.5 and args.neg_kind == "uniform":  # (side measurements on one GPU only: no rank waits for another's)
             # the realistic mixes beside the headline: NEG-1 negatives (a positive with one substituted base: shares minimizer and
             # flanks, so it reaches the k-mer verification) and positives only; same batch size, a few steps each
             mixes = {"neg_u_50_50": round(value, 2)}
@@ -429,7 +430,7 @@ def main():
             res["mixes_M_kmers_per_s_one_gpu"] = mixes
             step()  # `out` holds the headline batch's results again for the parity check below
             torch.cuda.synchronize(dev)
-        if not args.no_extra_mixes:
+        if n_gpus == 1 and not args.no_extra_mixes:
             # the step after k2u (get_ref_pos: PiscemUnitigTable occurrences -> MappedRefPos, src/index.rs:156-216) on the headline batch's
             # records: a synthetic tiling in which every unitig occurs once, occurrences packed into the minimal number of bits
             res["projection"] = bench_projection(ix, us, out, batch, dev, torch, np)
@@ -450,6 +451,7 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
+        D.barrier()  # every rank leaves the group at the same time
         dist.destroy_process_group()
 
 
