@@ -133,6 +133,17 @@ def launch_check(args):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(us_host, k, w, skew, seed, q_host, n_threads, target_s=8.0):
     """oracle ('port' of sshash.rs) timed on this box's host cores over a bounded sample: a pilot of
     1 M queries sizes the sample so that the timed region lasts about `target_s` seconds; then the single-threaded
@@ -440,7 +451,7 @@ def main():
             cb = cpu_baseline((words_h, us["total_len"], starts_h), k, args.w, args.skew, args.seed, q_host, cores)
             got = out[: 2 * cb["n"]].cpu().numpy().view(M.K2UPOS_DTYPE)
             same = got.tobytes() == cb["out"].tobytes()
-            res["cpu_baseline"] = {"value": round(cb["rate"], 3), "unit": "M k-mers/s", "cores": cores, "kind": "port",
+            res["cpu_baseline"] = {"value": round(cb["rate"], 3), "unit": "M k-mers/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
                                    "sample": f"first {cb['n']} queries of the rank-0 batch on the same {args.workload} index, "
                                              f"OpenMP static shards over {cores} threads (oracle build {cb['t_build']:.1f}s, query {cb['dt']:.1f}s)",
                                    "single_thread_ns_per_kmer": round(cb["ns_single"], 1),
