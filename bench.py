@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra-mixes", action="store_true", help="skip the NEG-1 and positives-only side measurements")
     ap.add_argument("--no-validate", dest="validate", action="store_false",
                     help="skip the correctness gate (K2U::validate_self on the device, every k-mer in both orientations) before timing")
+    ap.add_argument("--no-build-check", dest="build_check", action="store_false",
+                    help="do not validate the index after the build either (stage-cost experiments with kernel variants whose results are meaningless)")
     ap.add_argument("--host-build", action="store_true", help="build the index with the multi-threaded host builder instead of on the GPU")
     ap.add_argument("--mode", default="kmers", choices=["kmers", "reads"],
                     help="kmers: batched point queries (headline); reads: BASELINE config 3, every window of 150-bp reads "
@@ -341,7 +343,7 @@ def main():
     # host builder); duplicate 31-mers of the random background (a handful at this scale) are broken up and the index rebuilt,
     # so K2U::validate_self holds with no duplicate at all
     ix, validate, rebuilds = synth.build_index_unique(us, args.w, args.skew, args.seed, device=dev_index, on_device=not args.host_build,
-                                                      log=log if rank == 0 else None)
+                                                      log=log if rank == 0 else None, check=args.build_check)
     torch.cuda.synchronize(dev)
     t_build = time.time() - t0
     words_h = us["words"].cpu().numpy().view(np.uint64)

@@ -24,6 +24,12 @@ namespace mz {
         }                                                                                   \
     } while (0)
 
+// static instruction counts between points of a kernel: -DMZ_MARKS puts comments into the assembly (tools/count_marks.py)
+#ifdef MZ_MARKS
+#define MZ_MARK(name) asm volatile("; MZMARK " name)
+#else
+#define MZ_MARK(name) ((void)0)
+#endif
 constexpr int kBlock = 256;
 
 // Hit / miss / skipped tallies.  Lanes ballot and every wave keeps wave-uniform popcounts in
@@ -94,6 +100,13 @@ constexpr int kQpt = 4;                  // queries per thread
 constexpr int kTileQ = kBlock * kQpt;    // queries per tile
 constexpr unsigned long long kBestNone = ~0ull;
 constexpr uint32_t kPosBits = 36;
+// best[i] of a candidate: global k-mer position | kBestTwin when the k-mer, if it verifies, is the reverse complement of the query
+// (strand class of the entry xor strand of the query's canonical k-mer) | kBestUnk when the source of the candidate does not say
+// (skew-table slots) | bucket order << kBestOrderShift (stage S3: the smallest value is the first survivor)
+constexpr unsigned long long kBestTwin = 1ull << kPosBits, kBestUnk = 1ull << (kPosBits + 1);
+constexpr unsigned long long kBestDefer = ~0ull - 1; // after S5: the item waits in the wave's list of deferred exact walks
+constexpr uint32_t MZ_DEFER = 0xFFu;                 // match code of such an item (never leaves a kernel)
+constexpr uint32_t kBestOrderShift = kPosBits + 2;
 #ifndef MZ_SPECULATE
 #define MZ_SPECULATE 1
 #endif
@@ -111,6 +124,9 @@ constexpr int kStopAfter = MZ_STOP_AFTER;
 #ifndef MZ_WAVES_PER_EU
 #define MZ_WAVES_PER_EU 4
 #endif
+#ifndef MZ_READS_SF_LANES
+#define MZ_READS_SF_LANES 4 // lanes per minimizer line in stage SF of the reads kernel (tile_resolve)
+#endif
 #ifndef MZ_READS_WAVES
 #define MZ_READS_WAVES 3 // minimum waves per SIMD the reads kernel is compiled for (<= 168 VGPRs; at 2 the allocator takes 179 and the kernel runs 20 % slower)
 #endif
@@ -121,7 +137,9 @@ constexpr uint64_t kSlotInLine = 1ull << 63; // slot[i] (bucket start) points in
 // S.qinfo[i]: the flank16 an entry must show for item i (mz_common.hpp `pos` entry), in the orientation of the canonical
 // word g*: bits 0..7 = the 4 bases left of the minimizer in g*, bits 8..15 = the 4 bases right of it | offset << 16 |
 // kQMulti once a second bucket entry survived the flank filter
-constexpr uint32_t kQOffShift = 16, kQOffMask = 0x1Fu, kQMulti = 0x80000000u, kQIdle = 0x40000000u, kQClass = 1u << 21; // kQClass: the canonical k-mer is the reverse strand; // kQIdle: no query in this slot
+constexpr uint32_t kQOffShift = 16, kQOffMask = 0x1Fu, kQMulti = 0x80000000u, kQIdle = 0x40000000u, kQClass = 1u << 21, kQLine = 1u << 22;
+// kQClass: the canonical k-mer is the reverse strand; kQIdle: no query in this slot; kQLine: the survivors behind kQMulti are entries of the query's
+// minimizer line (front_walk serves)
 __device__ __forceinline__ uint32_t query_flank(uint64_t g, uint32_t off, uint32_t w) {
     const uint32_t ql = (uint32_t)(off >= kFlankBases ? g >> (2 * (off - kFlankBases)) : g << (2 * (kFlankBases - off))) & 0xFFu;
     const uint32_t qr = (uint32_t)(g >> (2 * (off + w))) & 0xFFu;
@@ -170,7 +188,7 @@ struct TileLdsT {
     ListT list_a[NT * kQpt], list_b[NT * kQpt];
     uint32_t cnt_a, cnt_b, cnt_skew, wave_tot[NT / 64];
 #ifdef MZ_DEBUG_COUNT
-    uint32_t dbg[4]; // scratch builds only (tools/ab_build.sh -DMZ_DEBUG_COUNT=n): S3 entries, S5 candidates, exact walks, runs of the tile
+    uint32_t dbg[6]; // scratch builds only (tools/ab_build.sh -DMZ_DEBUG_COUNT=n): S3 entries, S5 candidates (grouped: records gathered), exact walks, runs of the tile, exact walks that are not walks of a minimizer line
 #endif
 #ifdef MZ_LDS_PAD
     uint64_t pad[MZ_LDS_PAD * NT / 64];
@@ -310,6 +328,19 @@ __device__ __forceinline__ void tile_mphf(TileLdsT<SC::NT> &S, const MphfView &m
 // ---- tile producer / consumer API ------------------------------------------------------
 // A kernel fills the tile with tile_set_query() (S0), calls tile_resolve() (S1-S4) from uniform
 // control flow, then reads each item's answer with tile_result() (S5).
+// the exact in-order walk of an item's bucket (sshash.rs:494-552), for the few items whose recorded candidates all failed although
+// more entries had agreeing flanks.  MZ_WALK_CALL: compiled as a real function, so that its ~1500 instructions and its register
+// needs stay out of the kernels' main path.
+#ifndef MZ_WALK_CALL
+#define MZ_WALK_CALL 0
+#endif
+__device__ mz_k2upos front_walk(const IndexView &ix, uint64_t fw, uint64_t rc, uint32_t off_a);
+#if MZ_WALK_CALL
+__device__ __attribute__((noinline))
+#else
+__device__ __forceinline__
+#endif
+mz_k2upos exact_walk(const IndexView &ix, uint64_t fw, uint32_t qi);
 template <class SC>
 __device__ __forceinline__ void tile_begin(TileLdsT<SC::NT> &S) {
     if (SC::tid() == 0) { S.cnt_a = 0; S.cnt_b = 0; S.cnt_skew = 0; }
@@ -321,32 +352,84 @@ __device__ __forceinline__ uint32_t flank_cover_mask(uint32_t off, uint32_t room
 }
 constexpr uint32_t kFrontIdleKey = 0x100u << kFrontKeyShift; // key field no slot can show (real keys use at most 8 bits, empty slots all nine)
 
-// `lines`: the index has minimizer lines (keys fit 32 bits): the slot pattern of the query and its mask are prepared here,
-// once per query, for stage SF (pattern in the high half of slot[], mask in eoff[], which S3 only needs later)
+// `lines`: the index has minimizer lines (keys fit 32 bits): the line of the query, its slot pattern (kind 0, the key's low and
+// tag bits, the flanks) and the pattern's mask are prepared here, once per query, for stage SF (line in the low half of slot[],
+// pattern in the high half, mask in eoff[], which S3 only needs later)
 template <class SC>
-__device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, uint64_t fw, uint64_t rc, Minimizer mn, uint32_t k, uint32_t w, bool valid,
+__device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, uint64_t fw, uint64_t rc, Minimizer mn, const IndexView &ix, bool valid,
                                                bool lines) {
+    const uint32_t k = ix.k, w = ix.w;
     const uint32_t fl = query_flank(fw <= rc ? fw : rc, mn.offset, w);
     S.fw[i] = fw;
     S.qinfo[i] = fl | (mn.offset << kQOffShift) | (valid ? 0u : kQIdle) | (fw <= rc ? 0u : kQClass);
     S.best[i] = kBestNone;
     S.n[i] = valid ? 0u : kNIdle;
     if (lines) {
-        const uint32_t pat = (fl << kFrontFlankShift) | (valid ? 0u : kFrontIdleKey); // kind 0 (entry), these flanks; the key's low bits are added in SF
-        S.slot[i] = mn.word | ((uint64_t)pat << 32);
+        const uint32_t key = (uint32_t)mn.word, g = ix.front.g, gl = 2 * w - ix.front.t; // word = tag | line index | low g bits: tag starts at bit gl
+        const uint32_t pat = (fl << kFrontFlankShift) | (front_keyfield(key, g, gl) << kFrontKeyShift) | (valid ? 0u : kFrontIdleKey); // (an idle slot has key 0: line 0 is always there)
+        S.slot[i] = (uint64_t)((key >> g) & (uint32_t)(ix.front.n_lines - 1)) | ((uint64_t)pat << 32);
         S.eoff[i] = 3u | kFrontKeyMask | (flank_cover_mask(mn.offset, k - w - mn.offset) << kFrontFlankShift);
     } else {
         S.slot[i] = mn.word;
     }
 }
 
+// first entry of the key's bucket, in bucket order, that verifies -- lookup() for a query whose bucket lies inline in its
+// minimizer line (`off_a`: offset of the minimizer in the canonical k-mer).  The slow path of a window whose line held more
+// than one entry with matching flanks and whose first one failed: the line is scanned again and every surviving entry is
+// verified in turn, exactly as sshash.rs:494-552 walks the bucket.
+__device__ __forceinline__ mz_k2upos front_walk(const IndexView &ix, uint64_t fw, uint64_t rc, uint32_t off_a) {
+    const uint32_t k = ix.k, w = ix.w, g = ix.front.g, gl = 2 * w - ix.front.t;
+    const uint64_t gs = fw <= rc ? fw : rc;
+    const uint32_t key = (uint32_t)((gs >> (2 * off_a)) & kmer_mask(w));
+    const uint64_t *line = ix.front.lines + (uint64_t)((key >> g) & (uint32_t)(ix.front.n_lines - 1)) * kFrontSlots;
+    const uint32_t pat = (query_flank(gs, off_a, w) << kFrontFlankShift) | (front_keyfield(key, g, gl) << kFrontKeyShift);
+    const uint32_t msk = 3u | kFrontKeyMask | (flank_cover_mask(off_a, k - w - off_a) << kFrontFlankShift);
+    uint32_t alive = 0;
+#pragma unroll 1
+    for (uint32_t j0 = 0; j0 < kFrontSlots / 2; j0 += 2) { // (a rare path: few registers rather than all loads at once)
+        const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(line)[j0], b = reinterpret_cast<const ulonglong2 *>(line)[j0 + 1];
+        const uint32_t m = ((((uint32_t)a.x ^ pat) & msk) == 0 ? 1u : 0u) | ((((uint32_t)a.y ^ pat) & msk) == 0 ? 2u : 0u) |
+                           ((((uint32_t)b.x ^ pat) & msk) == 0 ? 4u : 0u) | ((((uint32_t)b.y ^ pat) & msk) == 0 ? 8u : 0u);
+        alive |= m << (2 * j0);
+    }
+    while (alive) {
+        const uint64_t e = line[__ffs((int)alive) - 1];
+        alive &= alive - 1;
+        const uint64_t p = (e >> kFrontPosShift) - (((e >> kFrontClsShift) & 1) ? k - w - off_a : off_a);
+        if (p > ix.total_len - k) continue;
+        const uint32_t mt = word_equivalency(fw, rc, read_kmer_i(ix.seqbv, p, k));
+        if (mt == MZ_NO_MATCH) continue;
+        const UnitigSpan sp = locate_unitig_i(ix.seqbv, p);
+        if (p + k <= sp.end) return make_hit(sp, p, mt);
+    }
+    return make_none();
+}
+#if MZ_WALK_CALL
+__device__ __attribute__((noinline))
+#else
+__device__ __forceinline__
+#endif
+mz_k2upos exact_walk(const IndexView &ix, uint64_t fw, uint32_t qi) {
+#ifdef MZ_WALK_NEVER
+    if (ix.seed != 0x0123456789abcdefull) return make_none(); // experiments only: the code is there, and never runs
+#endif
+    return (qi & kQLine) ? front_walk(ix, fw, kmer_rc(fw, ix.k), (qi >> kQOffShift) & kQOffMask) : lookup(ix, fw);
+}
 // kRuns: consecutive items of the tile tend to carry the same minimizer (the windows of a read): the direct-address stage then
 // reads one record per RUN of equal keys instead of one per item
 // kRowS0: a callable s0(q) that computes stage S0 of the items q * 64 + lane (wave scope only).  With minimizer lines, batch b
 // of stage SF needs only row b of the tile, so the rows are prepared one batch AHEAD: the S0 arithmetic of row b + 1 runs while
 // the lines of row b are in flight.  Callers without it fill the whole tile before they call tile_resolve.
 struct NoRowS0 { __device__ __forceinline__ void operator()(int) const {} };
-template <class SC, bool kRuns = false, class RowS0 = NoRowS0>
+// kFinish = false: the candidates are left in best[] (stages S0-S4 only) for a caller that verifies them itself
+// (tile_finish_grouped)
+// kSfLanes: lanes that fetch and scan the minimizer line of one query in stage SF: 8 (one 16-byte load each, the line as ONE request
+// of the wave) or 4 (two loads each, one per 64-byte half of the line: half as many rounds for the same lines -- fewer
+// instructions per query, for kernels that are bound by instruction issue and find most of their lines in the caches)
+// kDefer: an item that needs the exact walk is not walked here: its best[] becomes kBestDefer, tile_result() reports MZ_DEFER and the
+// kernel queues it (defer_push)
+template <class SC, bool kRuns = false, class RowS0 = NoRowS0, bool kFinish = true, int kSfLanes = 8, bool kDefer = false>
 __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexView &ix, RowS0 s0 = RowS0{}) {
     const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
     constexpr bool kHasS0 = !std::is_same<RowS0, NoRowS0>::value;
@@ -372,25 +455,27 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
 #ifndef MZ_SF_BATCH
 #define MZ_SF_BATCH 8
 #endif
-        constexpr int kFR = MZ_SF_BATCH;                       // rounds (of 8 queries) whose lines are in flight together
-        constexpr uint32_t kLpq = kFrontSlots / 2, kQpr = 64 / kLpq; // lanes per query (two slots each), queries per round
+        static_assert(kSfLanes == 8 || kSfLanes == 4, "lanes per line");
+        constexpr uint32_t kLpq = kSfLanes, kQpr = 64 / kLpq;  // lanes per query, queries per round
+        constexpr uint32_t kHalves = kFrontSlots / 2 / kLpq;    // 16-byte loads per lane: load h covers slots [8 h / kHalves ...) two per lane, i.e. lane `sub` holds slots (16 / kHalves) h + 2 sub, + 1
+        constexpr int kFR = MZ_SF_BATCH / (int)kHalves;          // rounds whose lines are in flight together (64 lines)
         constexpr uint32_t kRounds = 64 * kQpt / kQpr;          // per wavefront
-        const uint32_t lane = t & 63, sub = lane % kLpq, grp = lane / kLpq, g = ix.front.g;
-        const uint32_t gl = 2 * w - ix.front.t, line_mask = (uint32_t)(ix.front.n_lines - 1); // word = tag | line index | low g bits: tag starts at bit gl
+        const uint32_t lane = t & 63, sub = lane % kLpq, grp = lane / kLpq;
         const uint32_t wave_q0 = (t >> 6) * (64 * kQpt);      // first item of this wave's share of the tile
         const unsigned long long grp_mask = ((1ull << kLpq) - 1) << (lane & ~(kLpq - 1)), low_mask = grp_mask & ((1ull << lane) - 1); // my query's lanes / those before me
         static_assert(!kHasS0 || kFR * kQpr == 64, "one SF batch per row of the tile");
         if constexpr (kHasS0) { s0(0); SC::sync(); }
 #pragma unroll
         for (uint32_t r0 = 0; r0 < kRounds; r0 += kFR) { // (a rolling window of requests instead of batches measured the same: the gathers are bandwidth-bound)
-            ulonglong2 sl[kFR];
+            ulonglong2 sl[kFR][kHalves];
             uint32_t pat[kFR];
 #pragma unroll
             for (int a = 0; a < kFR; ++a) { // all loads of the batch first
-                const uint64_t kp = S.slot[wave_q0 + (r0 + a) * kQpr + grp];     // key | pattern << 32 (an idle slot has key 0: line 0 is always there)
-                const uint32_t key = (uint32_t)kp;
-                pat[a] = (uint32_t)(kp >> 32) | (front_keyfield(key, g, gl) << kFrontKeyShift);
-                sl[a] = *reinterpret_cast<const ulonglong2 *>(ix.front.lines + (uint64_t)((key >> g) & line_mask) * kFrontSlots + 2 * sub);
+                const uint64_t lp = S.slot[wave_q0 + (r0 + a) * kQpr + grp];     // line | pattern << 32
+                pat[a] = (uint32_t)(lp >> 32);
+                const uint64_t *line = ix.front.lines + (uint64_t)(uint32_t)lp * kFrontSlots + 2 * sub;
+#pragma unroll
+                for (uint32_t h = 0; h < kHalves; ++h) sl[a][h] = *reinterpret_cast<const ulonglong2 *>(line + h * (kFrontSlots / kHalves));
             }
             if constexpr (kHasS0) {
                 if (r0 / kFR + 1 < (uint32_t)kQpt) { s0((int)(r0 / kFR) + 1); SC::sync(); } // the next row, while this row's lines are in flight
@@ -398,18 +483,31 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
 #pragma unroll
             for (int a = 0; a < kFR; ++a) {
                 const uint32_t q = wave_q0 + (r0 + a) * kQpr + grp, msk = S.eoff[q];
-                const uint64_t e0 = sl[a].x, e1 = sl[a].y;
-                const uint32_t x0 = (uint32_t)e0 ^ pat[a], x1 = (uint32_t)e1 ^ pat[a];
-                const bool s0 = (x0 & msk) == 0, s1 = (x1 & msk) == 0; // an entry (kind 0) of this key whose flanks agree
-                const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
-                if ((s0 || s1) && ((b0 | b1) & low_mask) == 0) {       // slots run in line order, two per lane: this lane holds the first survivor
-                    S.best[q] = s0 ? e0 : e1;
-                    if (__popcll(b0 & grp_mask) + __popcll(b1 & grp_mask) > 1) atomicOr(&S.qinfo[q], kQMulti);
+                bool first = false, marker = false, seen = false; // seen: an earlier half of the line holds a survivor of my query
+                uint64_t first_e = 0, marker_e = 0;
+                uint32_t n_alive = 0;
+#pragma unroll
+                for (uint32_t h = 0; h < kHalves; ++h) {
+                    const uint64_t e0 = sl[a][h].x, e1 = sl[a][h].y;
+                    const uint32_t x0 = (uint32_t)e0 ^ pat[a], x1 = (uint32_t)e1 ^ pat[a];
+                    const bool s0 = (x0 & msk) == 0, s1 = (x1 & msk) == 0; // an entry (kind 0) of this key whose flanks agree
+                    const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
+                    if ((s0 || s1) && !seen && ((b0 | b1) & low_mask) == 0) { // slots run in line order, two per lane and half: this lane holds the first survivor
+                        first = true;
+                        first_e = s0 ? e0 : e1;
+                    }
+                    n_alive += (uint32_t)(__popcll(b0 & grp_mask) + __popcll(b1 & grp_mask));
+                    if constexpr (kHalves > 1) seen = seen || ((b0 | b1) & grp_mask) != 0;
+                    // heavy or spill marker of this key: same key bits, kind 1 or 2 (a key has entries or one marker, never both)
+                    const bool m0 = (x0 & (kFrontKeyMask | 3u)) - 1u < 2u, m1 = (x1 & (kFrontKeyMask | 3u)) - 1u < 2u;
+                    if (m0 || m1) { marker = true; marker_e = m0 ? e0 : e1; }
                 }
-                // heavy or spill marker of this key: same key bits, kind 1 or 2 (a key has entries or one marker, never both)
-                const bool m0 = (x0 & (kFrontKeyMask | 3u)) - 1u < 2u, m1 = (x1 & (kFrontKeyMask | 3u)) - 1u < 2u;
-                if (m0 || m1) {
-                    S.slot[q] = m0 ? e0 : e1;
+                if (first) {
+                    S.best[q] = first_e;
+                    if (n_alive > 1) atomicOr(&S.qinfo[q], kQMulti | kQLine);
+                }
+                if (marker) {
+                    S.slot[q] = marker_e;
                     S.n[q] = kNPending;
                 }
             }
@@ -422,9 +520,10 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
             const uint32_t nn = S.n[i];
             if (b != kBestNone) {
                 const uint32_t qi = S.qinfo[i], off_a = (qi >> kQOffShift) & kQOffMask;
-                const uint64_t p = (b >> kFrontPosShift) - (((b >> kFrontClsShift) & 1) ? k - w - off_a : off_a);
+                const uint32_t cls = (uint32_t)(b >> kFrontClsShift) & 1u;
+                const uint64_t p = (b >> kFrontPosShift) - (cls ? k - w - off_a : off_a);
                 const bool in_range = p <= ix.total_len - k;          // p wraps around when the k-mer would start before base 0
-                S.best[i] = in_range ? p : 0;                          // out of range (first or last bases of the sequence only): exact walk
+                S.best[i] = in_range ? p | ((cls != 0) != ((qi & kQClass) != 0) ? kBestTwin : 0ull) : 0;  // out of range (first or last bases of the sequence only): exact walk
                 if (!in_range) S.qinfo[i] = qi | kQMulti;
             }
             bool heavy = false;
@@ -813,7 +912,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 if ((((cls && !canon[a] ? flank_revcomp(fl) : fl) ^ qi) & mask) != 0 || mm_pos < off || mm_pos - off > last_km_start) continue;
                 // the first survivor in bucket order is the item's candidate (verified in S5); a second one is only flagged
                 const uint64_t jj = jdx[a] < 0x3FFFFFFu ? jdx[a] : 0x3FFFFFFu;
-                const unsigned long long old = atomicMin(&S.best[i], (jj << (kPosBits + 1)) | (mm_pos - off));
+                const unsigned long long old = atomicMin(&S.best[i], (jj << kBestOrderShift) | (cls != ((qi & kQClass) != 0) ? kBestTwin : 0ull) | (mm_pos - off));
                 if (old != kBestNone && !(qi & kQMulti)) S.qinfo[i] = qi | kQMulti;
             }
         }
@@ -835,7 +934,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
             const uint32_t n_match = (uint32_t)(__popcll(b0) + __popcll(b1));
             if (const unsigned long long any = b0 | b1) {
                 const uint32_t fl = (uint32_t)__ffsll((long long)any) - 1;
-                if (s4_lane == fl) S.best[rq.item] = (((b0 >> fl) & 1) ? e0 : e1) & ((1ull << kSkewPosBits) - 1);
+                if (s4_lane == fl) S.best[rq.item] = ((((b0 >> fl) & 1) ? e0 : e1) & ((1ull << kSkewPosBits) - 1)) | kBestUnk;
             }
             if (s4_sub == 0 && (be == 0 || n_match > 1)) {
                 S.qinfo[rq.item] |= kQMulti;
@@ -847,6 +946,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
         SC::sync();
     }
     if constexpr (kStopAfter == 4) return;
+    if constexpr (!kFinish) return;
     // ---- S5: every item has at most one recorded candidate position.  ONE gather of its 64-byte sequence+boundary record
     //          verifies the k-mer (sshash.rs:500-504) and yields unitig id / offset / length (:509-514); the answer is parked
     //          in the item's own slot[] / n[] words, which are dead by now.  Candidates are compacted first, so the gathers
@@ -860,7 +960,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
     {
         const uint32_t nc = S.cnt_a;
 #ifdef MZ_DEBUG_COUNT
-        if (t == 0) { S.dbg[1] = nc; S.dbg[2] = 0; }
+        if (t == 0) { S.dbg[1] = nc; S.dbg[2] = 0; S.dbg[3] = 0; S.dbg[4] = 0; S.dbg[5] = 0; }
         SC::sync();
 #endif
 #ifndef MZ_CPT
@@ -889,19 +989,26 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                 const uint32_t mt = word_equivalency(fw, rc, kw[a]);
                 const UnitigSpan sp = locate_boundary(bd[a], cp[a]);
                 mz_k2upos r = make_none();
+                bool defer = false;
                 if (mt != MZ_NO_MATCH && cp[a] + k <= sp.end) r = make_hit(sp, cp[a], mt);
-                else if (S.qinfo[i] & kQMulti) {
-                    r = lookup(ix, fw); // more than one survivor and the first one failed: exact in-order rescan
-#ifdef MZ_DEBUG_COUNT
-                    atomicAdd(&S.dbg[2], 1u);
+                else if (const uint32_t qi = S.qinfo[i]; qi & kQMulti) { // more than one survivor and the first one failed: exact in-order walk
+                    if constexpr (kDefer) {
+                        defer = true;
+                    } else {
+#ifndef MZ_NO_WALK
+                        r = exact_walk(ix, fw, qi);
 #endif
+#ifdef MZ_DEBUG_COUNT
+                        atomicAdd(&S.dbg[2], 1u);
+#endif
+                    }
                 }
                 if (r.match != MZ_NO_MATCH) {
                     S.slot[i] = ((uint64_t)r.unitig_id << 32) | r.unitig_len;
                     S.n[i] = r.pos;
                     S.best[i] = r.match == MZ_TWIN_MATCH ? 1ull : 0ull;
                 } else {
-                    S.best[i] = kBestNone;
+                    S.best[i] = defer ? kBestDefer : kBestNone;
                 }
             }
         }
@@ -917,8 +1024,217 @@ __device__ __forceinline__ mz_k2upos tile_result(const TileLdsT<SC::NT> &S, cons
     const unsigned long long b = S.best[i];
     if constexpr (kStopAfter != 0) return mz_k2upos{(uint32_t)S.slot[i], S.n[i], (uint32_t)b, MZ_NO_MATCH};
     if (b == kBestNone) return make_none();
+    if (b == kBestDefer) return mz_k2upos{0u, 0u, 0u, MZ_DEFER};
     const uint64_t s = S.slot[i];
     return mz_k2upos{(uint32_t)(s >> 32), S.n[i], (uint32_t)s, b ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH};
+}
+
+// ---- S5 for tiles whose items are consecutive base positions of reads (wave scope): verify and extend ------------------------
+// The windows of a read that hit lie at consecutive positions of a unitig -- ascending when the read runs along the stored
+// strand, descending when it runs against it, and on another unitig after a junction.  index/caching.rs:73-97 uses this one
+// window at a time and in one direction only (try pos + 1 on the same unitig, else a full lookup).  Here a whole stretch is
+// verified at once, in either direction: the candidates of the tile are grouped by (orientation, diagonal, sequence record) --
+// diagonal = candidate position minus the window's position in the tile for a read along the stored strand, plus it for
+// a read against it; a window whose candidate continues the group of the nearest earlier candidate joins it.  The first window
+// of a group (its leader) fetches the 64-byte sequence+boundary record ONCE and XORs its 128 bases with the tile's own bases
+// laid along the group's diagonal (the reverse-complemented tile for a read against the strand): the XOR is zero exactly where
+// read and unitig agree, so it holds the matching stretch of the whole group, however far it extends to either side of the
+// leader.  Every window of the group then tests the 2k bits of its own k-mer in the stashed XOR (sshash.rs:500-504) and
+// locates its unitig from the stashed boundary half (:509-514).  One dependent round trip to HBM per tile and a handful of
+// gathers (one per ~27 candidates on the GRCh38-shaped reads), where the per-candidate form (stage S5 of tile_resolve) makes
+// two round trips for ~180 gathers; and no window computes a reverse complement or compares k-mer words.  Every answer is
+// still that of the window's own lookup: a window joins a group only through the candidate its own lookup produced.
+// Candidates whose orientation is unknown (skew table) lead a group of their own with the raw record stashed.
+// The stash reuses words of the tile that are dead after stage S4: slot[] (32 records) and n[] + eoff[] (32 more).
+// `aligned`: words 0..14 = three pad words + the tile's 2-bit packed bases (12 words: 256 positions, the k-1 tail, junk), words
+// 15..30 = the reverse complement of those 12 words (position x' there = complement of tile position 383 - x') + 4 junk words.
+// Results come back in registers: res[q] answers item q * 64 + lane.
+constexpr uint32_t kAlignPad = 3, kAlignTileWords = kQpt * 2 + 4, kAlignRcAt = kAlignPad + kAlignTileWords, kAlignWords = (kAlignRcAt + kAlignTileWords + 4 + 1) & ~1u;
+// Stash slot of a group (12 words): w0..w3 = record bases xor the tile's bases along the diagonal (the raw record for a candidate of
+// unknown orientation); w4, w5 = boundary bits of the record's 128 bases; w6, w7 = per 32-base quarter j = 0..2 of the record a
+// 32-bit table { boundaries below the quarter | (position + 1 of the highest boundary below the quarter, 0 = none) << 8 |
+// (position + 1 of the lowest boundary above the quarter, 0 = none) << 16 } so that a window locates its unitig from ONE 32-bit
+// piece of the boundary bits (rank, start and end as locate_unitig_r gives them), then the id of the unitig holding the record's
+// first base; w8 = start of that unitig, w9 = end of the unitig holding the record's last base.
+// The stash lives in words that are dead by now: n[] + eoff[] of the tile (21 slots) and `stash_b`, kStashBWords words lent by
+// the caller (the window keys of the reads kernel: 24 slots).
+constexpr uint32_t kStashWords = 12, kStashA = 2048 / (8 * kStashWords), kStashBWords = 2 * (64 * kQpt + 32) / 2, kStashB = kStashBWords / kStashWords, kStashSlots = kStashA + kStashB;
+// emit(q, r): called once for every item q * 64 + lane with its answer r -- except the items of the returned mask (bit q: item
+// q * 64 + lane), which need the exact in-order walk (the caller queues them: defer_push)
+template <class SC, class Emit>
+__device__ __forceinline__ uint32_t tile_finish_grouped(TileLdsT<SC::NT> &S, const IndexView &ix, const uint64_t *aligned, uint64_t *stash_b, Emit emit) {
+    static_assert(SC::NT == 64, "items are numbered along the wave's tile");
+    using Lds = TileLdsT<SC::NT>;
+    static_assert(offsetof(Lds, eoff) == offsetof(Lds, n) + sizeof(uint32_t) * 64 * kQpt && offsetof(Lds, n) % 16 == 0 && sizeof(uint32_t) * (2 * 64 * kQpt + 1) >= 2048 &&
+                      (kStashWords * 8) % 16 == 0, "stash slots in n[] + eoff[]");
+    const uint32_t lane = SC::tid(), k = ix.k;
+    const unsigned long long lt_mask = (1ull << lane) - 1, le_mask = lt_mask | (1ull << lane);
+    constexpr uint64_t kPosMask = (1ull << kPosBits) - 1;
+    constexpr uint32_t kTileBases = 32 * kAlignTileWords, kNoSlot = ~0u;
+    MZ_MARK("FIN_A");
+    uint32_t sidx[kQpt];                                          // stash slot (number of the group) of my window's candidate; kNoSlot: none
+    uint32_t n_lead = 0, carry_a = ~0u, carry_b = 0, carry_slot = 0; // uniform; key and group of the latest candidate of the rows before
+    bool any_unk = false;
+#pragma unroll
+    for (int q = 0; q < kQpt; ++q) {
+        const uint32_t i = q * 64 + lane;
+        const unsigned long long b = S.best[i];
+        const bool has = b != kBestNone, twin = (b & kBestTwin) != 0, unk = has && (b & kBestUnk) != 0;
+        const uint64_t p = b & kPosMask;
+        uint32_t off;
+        // key: record | orientation << 30 | unknown << 31 (records are < 2^30), and the low half of the diagonal (two candidates in
+        // one record lie fewer than 128 positions apart, so equal low halves are equal diagonals)
+        const uint32_t ka = has ? (uint32_t)seq_rec_of(p, off) | (twin ? 1u << 30 : 0u) | (unk ? 1u << 31 : 0u) : ~0u;
+        const uint32_t kb = twin ? (uint32_t)p + i : (uint32_t)p - i;
+        const unsigned long long has_b = __ballot(has), before = has_b & lt_mask;
+        const uint32_t src = before ? 63u - (uint32_t)__clzll(before) : lane;        // nearest earlier window with a candidate
+        uint32_t pa = (uint32_t)__shfl((int)ka, (int)src), pb = (uint32_t)__shfl((int)kb, (int)src);
+        if (!before) { pa = carry_a; pb = carry_b; }
+        const bool lead = has && (pa != ka || pb != kb || unk);
+        const unsigned long long lead_b = __ballot(lead), mine = lead_b & le_mask;
+        const uint32_t slot = mine ? n_lead + (uint32_t)__popcll(mine) - 1u : carry_slot; // the candidates between a leader and me continue its group
+        sidx[q] = has ? slot : kNoSlot;
+        if (lead) S.list_a[n_lead + (uint32_t)__popcll(lead_b & lt_mask)] = (typename Lds::ListT)i;
+        if (has_b) {
+            const int lastl = 63 - __clzll(has_b);
+            carry_a = (uint32_t)__builtin_amdgcn_readlane((int)ka, lastl);
+            carry_b = (uint32_t)__builtin_amdgcn_readlane((int)kb, lastl);
+            carry_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, lastl);
+        }
+        n_lead += (uint32_t)__popcll(lead_b);
+        any_unk = any_unk || __ballot(unk) != 0;
+    }
+    MZ_MARK("FIN_A_END");
+    SC::sync();
+#ifdef MZ_DEBUG_COUNT
+    if (lane == 0) { S.dbg[1] = n_lead; S.dbg[2] = 0; }
+#endif
+    auto stash = [&](uint32_t j) -> uint64_t * { return j < kStashA ? reinterpret_cast<uint64_t *>(S.n) + j * kStashWords : stash_b + (j - kStashA) * kStashWords; };
+    uint32_t walk = 0; // bit q: item q * 64 + lane needs the exact in-order walk
+    for (uint32_t base = 0; base < n_lead; base += kStashSlots) { // uniform; one round unless more than kStashSlots groups start in the tile
+        {
+            MZ_MARK("FIN_LEAD");
+            const bool act = lane < kStashSlots && base + lane < n_lead;
+            const uint32_t item = S.list_a[act ? base + lane : 0u];
+            const unsigned long long b = S.best[item];
+            const uint64_t p = (b & kPosMask) <= ix.total_len - k ? b & kPosMask : 0ull; // (a candidate is always a k-mer position of the sequence; never trust a gather address blindly)
+            uint32_t off;
+            const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(ix.seqbv + seq_rec_of(p, off) * kSeqRecWords); // idle lanes re-read the first leader's record
+            const ulonglong2 r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+            // the tile's bases along the diagonal: record base y <-> aligned position a0 + y
+            const bool twin = (b & kBestTwin) != 0;
+            const uint32_t a0 = twin ? 32 * kAlignRcAt + (kTileBases - item - k) - off : 32 * kAlignPad + item - off; // in bases from word 0 of `aligned`
+            const uint32_t W = a0 >> 5, sh = 2 * (a0 & 31);
+            uint64_t A[5], X[4];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) A[j] = aligned[W + j];
+            const uint64_t raw = (b & kBestUnk) ? 0ull : ~0ull;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) X[j] = ((A[j] >> sh) | ((A[j + 1] << 1) << (63 - sh))) & raw;
+            // boundary tables of the quarters 0..2 (a window starts in the first 96 bases of its record)
+            const uint32_t q0 = (uint32_t)r3.x, q1 = (uint32_t)(r3.x >> 32), q2 = (uint32_t)r3.y, q3 = (uint32_t)(r3.y >> 32);
+            const uint32_t c1 = (uint32_t)__popc(q0), c2 = c1 + (uint32_t)__popc(q1);
+            const uint32_t hi1 = q0 ? 32u - (uint32_t)__clz((int)q0) : 0u, hi2 = q1 ? 64u - (uint32_t)__clz((int)q1) : hi1; // highest boundary below quarter 1 / 2
+            const uint32_t lo3 = q3 ? 96u + (uint32_t)__ffs((int)q3) : 0u, lo2 = q2 ? 64u + (uint32_t)__ffs((int)q2) : lo3, lo1 = q1 ? 32u + (uint32_t)__ffs((int)q1) : lo2; // lowest boundary from quarter 3 / 2 / 1 on
+            const uint32_t t0 = lo1 << 16, t1 = c1 | (hi1 << 8) | (lo2 << 16), t2 = c2 | (hi2 << 8) | (lo3 << 16);
+            if (act) {
+                ulonglong2 *st = reinterpret_cast<ulonglong2 *>(stash(lane));
+                st[0] = ulonglong2{r0.x ^ X[0], r0.y ^ X[1]};
+                st[1] = ulonglong2{r1.x ^ X[2], r1.y ^ X[3]};
+                st[2] = r3;
+                st[3] = ulonglong2{t0 | ((uint64_t)t1 << 32), t2 | ((r2.x & 0xFFFFFFFFull) << 32)};
+                st[4] = ulonglong2{(r2.x >> 32) | ((r2.y >> 36) << 32), r2.y & ((1ull << 36) - 1)};
+            }
+        }
+        MZ_MARK("FIN_LEAD_END");
+        SC::sync();
+#pragma unroll
+        for (int q = 0; q < kQpt; ++q) {
+            MZ_MARK("FIN_WIN");
+            if (sidx[q] - base >= kStashSlots) continue;        // no candidate, or a group of another round
+            const uint32_t i = q * 64 + lane;
+            const uint64_t *st = stash(sidx[q] - base);
+            const unsigned long long b = S.best[i];
+            const uint64_t p = b & kPosMask;
+            uint32_t off;
+            const uint64_t rbase = seq_rec_of(p, off) * kSeqRecStride;
+            const uint32_t wi = off >> 5, sh = 2 * (off & 31);
+            const uint64_t lo = st[wi], hi = st[wi + 1];
+            const uint64_t x = ((lo >> sh) | ((hi << 1) << (63 - sh))) & kmer_mask(k);
+            uint32_t mt = x == 0 ? ((b & kBestTwin) ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH) : MZ_NO_MATCH;
+            if (any_unk) { // (uniform) a skew-table candidate says nothing about its orientation: compare words
+                const uint32_t ti = 32 * kAlignPad + i, tw = ti >> 5, ts = 2 * (ti & 31);
+                const uint64_t fw = ((aligned[tw] >> ts) | ((aligned[tw + 1] << 1) << (63 - ts))) & kmer_mask(k);
+                if (b & kBestUnk) mt = word_equivalency(fw, kmer_rc(fw, k), x);
+            }
+            // unitig of the window from the quarter of the boundary bits that holds its first base
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(st);
+            const uint32_t dq = s32[8 + wi], tab = s32[12 + wi], id0 = s32[15], bi = off & 31;
+            const uint32_t below = dq & ~(~0u << bi), above = dq >> bi;
+            const uint32_t rank = (tab & 0xFFu) + (uint32_t)__popc(below);
+            const uint32_t srel = below ? 32 * wi + 32 - (uint32_t)__clz((int)below) : (tab >> 8) & 0xFFu; // position + 1 of the last boundary before the window, 0: none in the record
+            const uint32_t erel = above ? off + (uint32_t)__ffs((int)above) : tab >> 16;                    // position + 1 of the first boundary at or after it, 0: none
+            const ulonglong2 se = *reinterpret_cast<const ulonglong2 *>(st + 8);
+            UnitigSpan sp;
+            sp.id = id0 + rank;
+            sp.start = srel ? rbase + srel : se.x;
+            sp.end = erel ? rbase + erel : se.y;
+            MZ_MARK("FIN_WIN_LOC");
+            if (mt != MZ_NO_MATCH && p + k <= sp.end) { emit(q, make_hit(sp, p, mt)); sidx[q] = kNoSlot - 1; } // (answered)
+            else if (S.qinfo[i] & kQMulti) { walk |= 1u << q; sidx[q] = kNoSlot - 1; }
+        }
+        MZ_MARK("FIN_WIN_END");
+        SC::sync(); // the next round overwrites the stash
+    }
+#pragma unroll
+    for (int q = 0; q < kQpt; ++q)
+        if (sidx[q] != kNoSlot - 1) emit(q, make_none()); // no candidate, or one that failed
+    MZ_MARK("FIN_END");
+    return walk;
+}
+
+// ---- deferred exact walks ----------------------------------------------------------------------------------------------
+// An item whose recorded candidate failed although more entries of its bucket had agreeing flanks needs the exact in-order
+// walk of the bucket (sshash.rs:494-552): a chain of dependent loads that ONE lane follows while the other 63 of its wave
+// wait -- about 15 microseconds a time, for 0.3 % of the windows of the GRCh38-shaped reads, which used to be a fifth of
+// that kernel's time.  The wave-scoped kernels therefore do not walk on the spot: the item (where its answer goes, its forward
+// word, what the walk needs of its flags) is queued in a small per-wave list, and when kDeferCap have gathered -- and at the
+// end of the kernel -- one pass walks them all, a lane each, their loads in flight together.
+constexpr uint32_t kDeferCap = 16;
+struct DeferLds {
+    uint64_t where[kDeferCap]; // index of the answer in the output array | minimizer offset << 58 | kQLine << 63
+    uint64_t fw[kDeferCap];
+};
+// walks the queued items: lane j takes entry j; store(where, r) writes an answer
+template <class Store>
+__device__ __forceinline__ void defer_flush(const DeferLds &D, uint32_t cnt, const IndexView &ix, Tally &tally, Store store) {
+    const uint32_t lane = __lane_id();
+    const bool act = lane < cnt;
+    mz_k2upos r = make_none();
+    if (act) {
+        const uint64_t wh = D.where[lane];
+        r = exact_walk(ix, D.fw[lane], (uint32_t)((wh >> 58) & kQOffMask) << kQOffShift | ((wh >> 63) ? kQLine : 0u));
+        store(wh & ((1ull << 58) - 1), r);
+    }
+    tally.add(act && r.match != MZ_NO_MATCH, act && r.match == MZ_NO_MATCH, false);
+    WaveScope::sync();
+}
+// queues the items of the lanes with `defer` (cnt: entries in the list, wave-uniform); a full list is flushed on the way
+template <class Flush>
+__device__ __forceinline__ void defer_push(DeferLds &D, uint32_t &cnt, bool defer, uint64_t where, uint64_t fw, uint32_t qi, Flush flush) {
+    unsigned long long db = __ballot(defer);
+    if (db == 0) return;
+    const uint32_t lane = __lane_id();
+    const uint64_t wh = where | ((uint64_t)((qi >> kQOffShift) & kQOffMask) << 58) | ((qi & kQLine) ? 1ull << 63 : 0ull);
+    while (db) {
+        const uint32_t room = kDeferCap - cnt, rank = (uint32_t)__popcll(db & ((1ull << lane) - 1));
+        if (((db >> lane) & 1) && rank < room) { D.where[cnt + rank] = wh; D.fw[cnt + rank] = fw; }
+        const uint32_t n = (uint32_t)__popcll(db), take = n < room ? n : room;
+        cnt += take;
+        for (uint32_t a = 0; a < take; ++a) db &= db - 1; // the lanes served
+        WaveScope::sync();
+        if (cnt == kDeferCap) { flush(); cnt = 0; }
+    }
 }
 
 // KW: compile-time (k << 8 | w) for the common configuration (constant shifts, masks and trip counts;
@@ -948,7 +1264,7 @@ __global__ __launch_bounds__(kBlock) void k2u_tile_kernel(IndexView ix, const ui
             uint32_t i = q * kBlock + t;
             uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
             uint64_t rc = kmer_rc(fw, k);
-            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), k, w, i < n_valid, ix.front.lines != nullptr);
+            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), ix, i < n_valid, ix.front.lines != nullptr);
         }
         tile_resolve<BlockScope>(S, ix);
         // ---- S5: coalesced 16-byte stores
@@ -974,12 +1290,16 @@ __global__ __launch_bounds__(kBlock, MZ_WAVES_PER_EU) void k2u_wave_kernel(Index
     using SC = WaveScope;
     constexpr int kWT = SC::NT * kQpt; // queries per wave tile
     __shared__ TileLdsT<SC::NT> SS[kBlock / 64];
+    __shared__ DeferLds DD[kBlock / 64];
     TileLdsT<SC::NT> &S = SS[threadIdx.x >> 6];
+    DeferLds &D = DD[threadIdx.x >> 6];
     const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
     const uint64_t kmask = kmer_mask(k);
     const uint64_t n_tiles = (n + kWT - 1) / kWT;
     const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (kBlock / 64);
     Tally tally;
+    uint32_t n_defer = 0; // queued exact walks (wave-uniform)
+    auto flush = [&]() { defer_flush(D, n_defer, ix, tally, [&](uint64_t where, const mz_k2upos &r) { out[where] = r; }); };
     for (uint64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
         const uint64_t base = tile * kWT;
         const uint32_t n_valid = (uint32_t)(n - base < (uint64_t)kWT ? n - base : (uint64_t)kWT);
@@ -994,25 +1314,28 @@ __global__ __launch_bounds__(kBlock, MZ_WAVES_PER_EU) void k2u_wave_kernel(Index
             const uint32_t i = q * SC::NT + t;
             const uint64_t fw = i < n_valid ? (fwq[q] & kmask) : 0;
             const uint64_t rc = kmer_rc(fw, k);
-            tile_set_query<SC>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), k, w, i < n_valid, ix.front.lines != nullptr);
+            tile_set_query<SC>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), ix, i < n_valid, ix.front.lines != nullptr);
         };
 #if MZ_ROW_S0
-        tile_resolve<SC, false>(S, ix, s0_row);
+        tile_resolve<SC, false, decltype(s0_row), true, 8, true>(S, ix, s0_row);
 #else
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) s0_row(q);
-        tile_resolve<SC>(S, ix);
+        tile_resolve<SC, false, NoRowS0, true, 8, true>(S, ix);
 #endif
 #pragma unroll
         for (int q = 0; q < kQpt; ++q) {
             uint32_t i = q * SC::NT + t;
             bool act = i < n_valid;
             mz_k2upos r = act ? tile_result<SC>(S, ix, i) : make_none();
-            if (act) out[base + i] = r;
-            tally.add(act && r.match != MZ_NO_MATCH, act && r.match == MZ_NO_MATCH, false);
+            const bool defer = act && r.match == MZ_DEFER; // answered later, by the pass over the wave's deferred exact walks
+            if (act && !defer) out[base + i] = r;
+            tally.add(act && !defer && r.match != MZ_NO_MATCH, act && !defer && r.match == MZ_NO_MATCH, false);
+            defer_push(D, n_defer, defer, base + i, S.fw[i], S.qinfo[i], flush);
         }
         SC::sync();
     }
+    if (n_defer) flush();
     tally.flush(counts);
 }
 
@@ -1033,7 +1356,7 @@ __global__ __launch_bounds__(kBlock) void k2u_compact_kernel(IndexView ix, const
             uint32_t i = q * kBlock + t;
             uint64_t fw = i < n_valid ? (fw_words[base + i] & kmask) : 0;
             uint64_t rc = kmer_rc(fw, k);
-            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), k, w, i < n_valid, ix.front.lines != nullptr);
+            tile_set_query<BlockScope>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), ix, i < n_valid, ix.front.lines != nullptr);
         }
         tile_resolve<BlockScope>(S, ix);
 #pragma unroll
@@ -1340,7 +1663,7 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
                     mn = window_minimizer(R, i, fw, rc, k, w);
                 }
             }
-            tile_set_query<SC>(S, it, fw, rc, mn, k, w, query, false); // (runs are resolved per leader: no per-item line pattern)
+            tile_set_query<SC>(S, it, fw, rc, mn, ix, query, false); // (runs are resolved per leader: no per-item line pattern)
             if (state[q] == 1) { // non-ACGT window: reported, never queried
                 mz_k2upos sk = make_none();
                 sk.match = MZ_SKIPPED;
@@ -1372,7 +1695,8 @@ constexpr int kWaveTile = 64 * kQpt;   // positions per wave tile
 constexpr int kWaveReadsStaged = 32;   // reads whose offsets are staged per wave tile
 struct alignas(16) ReadsWaveLds {
     uint64_t plane_lo[kQpt + 2], plane_hi[kQpt + 2], plane_inv[kQpt + 2]; // kQpt rows of 64 positions, the tail row, a pad word
-    uint64_t packed[kWaveTile / 32 + 4];                                    // 2-bit packed bases of the tile and its tail
+    uint64_t aligned[kAlignWords];                                          // pad words, the 2-bit packed bases of the tile and its tail (packed()), their reverse complement (tile_finish_grouped)
+    __device__ __forceinline__ uint64_t *packed() { return aligned + kAlignPad; }
     uint32_t keys_f[kWaveTile + 32], keys_r[kWaveTile + 32];                // window keys (see window_minima_17), then the window minima
     uint64_t roff[kWaveReadsStaged + 1], koff[kWaveReadsStaged + 1];
     uint64_t start_plane[kQpt];
@@ -1385,7 +1709,9 @@ __device__ __forceinline__ uint64_t packed_mer(const uint64_t *packed, uint32_t 
     const uint64_t lo = packed[wi], hi = packed[wi + 1];
     return ((lo >> sh) | ((hi << 1) << (63 - sh))) & kmer_mask(len);
 }
-template <bool kPerItemLines> // true: every window scans its minimizer line itself (stage SF), as a point query does; false: one lookup per run of windows
+// kPerItemLines: true: every window scans its minimizer line itself (stage SF), as a point query does; false: one lookup per run of windows
+// kGrouped: candidates are verified per group of windows that share a sequence record (tile_finish_grouped) instead of one by one
+template <bool kPerItemLines, bool kGrouped>
 __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
                                                                               const uint64_t *__restrict__ read_offsets,
                                                                               const uint64_t *__restrict__ kmer_offsets, uint64_t n_reads,
@@ -1394,6 +1720,7 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
     using SC = WaveScope;
     __shared__ TileLdsT<SC::NT> SS[kBlock / 64];
     __shared__ ReadsWaveLds RR[kBlock / 64];
+    __shared__ DeferLds DD[kBlock / 64];
     constexpr uint32_t k = 31, w = 15, n_win = k - w + 1, T = kWaveTile;
     static_assert(T + n_win - 1 <= kWaveTile + 32 - 12 && 4 * 63 + 19 < kWaveTile + 32, "keys of the tile and its 16-position tail");
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1405,6 +1732,9 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
     const uint64_t tile_first = wave_id * tiles_per_wave, tile_end = tile_first + tiles_per_wave < n_tiles ? tile_first + tiles_per_wave : n_tiles;
     uint64_t next_read0 = ~0ull; // read0 of the next tile when it is known, else ~0 (search)
     Tally tally;
+    DeferLds &D = DD[wave];
+    uint32_t n_defer = 0; // queued exact walks (wave-uniform)
+    auto flush = [&]() { defer_flush(D, n_defer, ix, tally, [&](uint64_t where, const mz_k2upos &r) { out[where] = r; }); };
 #ifndef MZ_READS_WAVE_PREFETCH
 #define MZ_READS_WAVE_PREFETCH 1 // the bases of tile + 1 are requested while tile is resolved (five registers held across the lookups: the kernel then sits exactly at its 168-register limit, without scratch; +6.5 %)
 #endif
@@ -1490,11 +1820,14 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
         if (lane < T / 32 + 4) { // the tile 2-bit packed: word j = bases [32 j, 32 j + 32)
             const uint32_t half = 32 * (lane & 1);
             const uint64_t pl = lane / 2 < kQpt + 2 ? R.plane_lo[lane / 2] : 0, ph = lane / 2 < kQpt + 2 ? R.plane_hi[lane / 2] : 0;
-            R.packed[lane] = spread_bits((uint32_t)(pl >> half)) | (spread_bits((uint32_t)(ph >> half)) << 1);
+            R.packed()[lane] = spread_bits((uint32_t)(pl >> half)) | (spread_bits((uint32_t)(ph >> half)) << 1);
         }
         SC::sync();
+        if constexpr (kGrouped) { // the tile reverse-complemented, word by word in reverse order (for the windows of reads that run against the stored strand)
+            if (lane < kAlignTileWords) R.aligned[kAlignRcAt + lane] = kmer_rc(R.packed()[kAlignTileWords - 1 - lane], 32);
+        }
         for (uint32_t j = lane; j < T + n_win - 1; j += 64) { // window keys of both strands (layout: window_minima_17)
-            const uint32_t m = (uint32_t)packed_mer(R.packed, j, w);
+            const uint32_t m = (uint32_t)packed_mer(R.packed(), j, w);
             R.keys_f[j] = (hash_mmer32(m, ix.seed) << kTilePosBits) | j;
             R.keys_r[j] = (hash_mmer32((uint32_t)kmer_rc(m, w), ix.seed) << kTilePosBits) | ((1u << kTilePosBits) - 1 - j);
         }
@@ -1537,13 +1870,13 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
             }
             const bool query = state[q] == 2;
             if (query) {
-                fw = packed_mer(R.packed, i, k);
+                fw = packed_mer(R.packed(), i, k);
                 rc = kmer_rc(fw, k);
                 const uint32_t key = fw <= rc ? R.keys_f[i] : R.keys_r[i], low = key & ((1u << kTilePosBits) - 1); // minimum key of the window
                 mn.offset = fw <= rc ? low - i : (k - w) - ((1u << kTilePosBits) - 1 - low - i);
                 mn.word = ((fw <= rc ? fw : rc) >> (2 * mn.offset)) & kmer_mask(w);
             }
-            tile_set_query<SC>(S, i, fw, rc, mn, k, w, query, kPerItemLines); // (runs are resolved per leader: no per-item line pattern)
+            tile_set_query<SC>(S, i, fw, rc, mn, ix, query, kPerItemLines); // (runs are resolved per leader: no per-item line pattern)
             if (state[q] == 1) { // non-ACGT window: reported, never queried
                 mz_k2upos sk = make_none();
                 sk.match = MZ_SKIPPED;
@@ -1554,25 +1887,48 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
 #ifndef MZ_READS_ROW_S0
 #define MZ_READS_ROW_S0 0 // 1: per-item form with the rows of the tile prepared inside stage SF, one batch of lines ahead, as the point kernel does (44 bytes of scratch per lane here: 21.4 against 23.5 G windows/s on S-human)
 #endif
-        if constexpr (kPerItemLines && MZ_READS_ROW_S0) {
-            tile_resolve<SC, false>(S, ix, s0_row);
-        } else {
+        if constexpr (kGrouped && kStopAfter == 0) {
 #pragma unroll
             for (int q = 0; q < kQpt; ++q) s0_row(q);
-            tile_resolve<SC, !kPerItemLines>(S, ix);
+            tile_resolve<SC, !kPerItemLines, NoRowS0, false, MZ_READS_SF_LANES>(S, ix);
+            uint32_t hits = 0; // bit q: the window of row q hit
+            auto emit = [&](int q, const mz_k2upos &r) {
+                if (state[q] == 2) {
+                    out[out_idx[q]] = r;
+                    if (r.match != MZ_NO_MATCH) hits |= 1u << q;
+                }
+            };
+            const uint32_t walk = tile_finish_grouped<SC>(S, ix, R.aligned, reinterpret_cast<uint64_t *>(R.keys_f), emit);
+#pragma unroll
+            for (int q = 0; q < kQpt; ++q) {
+                const bool pend = state[q] == 2, defer = pend && ((walk >> q) & 1u); // (answered later, by the pass over the wave's deferred exact walks)
+                tally.add(pend && !defer && ((hits >> q) & 1u), pend && !defer && !((hits >> q) & 1u), false);
+                defer_push(D, n_defer, defer, out_idx[q], S.fw[q * 64 + lane], S.qinfo[q * 64 + lane], flush);
+            }
+        } else {
+            if constexpr (kPerItemLines && MZ_READS_ROW_S0) {
+                tile_resolve<SC, false, decltype(s0_row), true, 8, true>(S, ix, s0_row);
+            } else {
+#pragma unroll
+                for (int q = 0; q < kQpt; ++q) s0_row(q);
+                tile_resolve<SC, !kPerItemLines, NoRowS0, true, MZ_READS_SF_LANES, true>(S, ix);
+            }
+#pragma unroll
+            for (int q = 0; q < kQpt; ++q) {
+                const bool pend = state[q] == 2;
+                const mz_k2upos res = pend ? tile_result<SC>(S, ix, q * 64 + lane) : make_none();
+                const bool defer = pend && res.match == MZ_DEFER;
+                if (pend && !defer) out[out_idx[q]] = res;
+                tally.add(pend && !defer && res.match != MZ_NO_MATCH, pend && !defer && res.match == MZ_NO_MATCH, false);
+                defer_push(D, n_defer, defer, out_idx[q], S.fw[q * 64 + lane], S.qinfo[q * 64 + lane], flush);
+            }
         }
 #ifdef MZ_DEBUG_COUNT
         tally.skipped += S.dbg[MZ_DEBUG_COUNT - 1];
 #endif
-#pragma unroll
-        for (int q = 0; q < kQpt; ++q) {
-            const bool pend = state[q] == 2;
-            mz_k2upos res = pend ? tile_result<SC>(S, ix, q * 64 + lane) : make_none();
-            if (pend) out[out_idx[q]] = res;
-            tally.add(pend && res.match != MZ_NO_MATCH, pend && res.match == MZ_NO_MATCH, false);
-        }
         SC::sync();
     }
+    if (n_defer) flush();
     tally.flush(counts);
 }
 
@@ -1623,8 +1979,8 @@ __global__ __launch_bounds__(kBlock, 4) void validate_self_kernel(IndexView ix, 
                 if (valid[q]) { fw = read_kmer_i(ix.seqbv, p, k); rc = kmer_rc(fw, k); }
             }
             Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
-            tile_set_query<SC>(S, i, fw, rc, mn, k, w, valid[q], ix.front.lines != nullptr);          // km
-            tile_set_query<SC>(S, kPos + i, rc, fw, mn, k, w, valid[q], ix.front.lines != nullptr);   // km.swap(): same canonical k-mer, same minimizer
+            tile_set_query<SC>(S, i, fw, rc, mn, ix, valid[q], ix.front.lines != nullptr);          // km
+            tile_set_query<SC>(S, kPos + i, rc, fw, mn, ix, valid[q], ix.front.lines != nullptr);   // km.swap(): same canonical k-mer, same minimizer
         }
         tile_resolve<SC>(S, ix);
 #pragma unroll
@@ -1862,6 +2218,9 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
     const bool use_lines = lines_env ? lines_env[0] != '0' : d.n_entries >= (1ull << 28);
     if (!use_lines && v.mm.direct) v.front.lines = nullptr;
     const char *rk = getenv("MZ_READS_KERNEL"); // "block": the workgroup-staged kernel also for (31, 15)
+    const char *vf = getenv("MZ_READS_VERIFY"); // "each": one sequence-record gather per candidate (stage S5) instead of one per group of windows
+    const bool grouped = !(vf && vf[0] == 'e');
+#define MZ_LAUNCH_READS(KERNEL, GRID) hipLaunchKernelGGL(KERNEL, GRID, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts)
     if (v.k == 31 && v.w == 15 && !(rk && rk[0] == 'b')) {
         const uint64_t n_wave_tiles = (n_bases + kWaveTile - 1) / kWaveTile;
         // workgroups per CU: 3 are resident; 24 give every slot eight shorter runs of tiles to even the finish out (measured 3: 31.0, 8: 30.3 --
@@ -1869,16 +2228,17 @@ int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_ba
         const char *ge = getenv("MZ_READS_GRID");
         const dim3 wgrid(tile_grid(d, (n_wave_tiles + kBlock / 64 - 1) / (kBlock / 64), ge && atoi(ge) > 0 ? (unsigned)atoi(ge) : 24u));
         const char *rr = getenv("MZ_READS_RESOLVE");
-        if (v.front.lines != nullptr && !(rr && rr[0] == 'r'))
-            hipLaunchKernelGGL(k2u_reads_wave_kernel<true>, wgrid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
-        else
-            hipLaunchKernelGGL(k2u_reads_wave_kernel<false>, wgrid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts);
-    } else if (v.k == 31 && v.w == 15)
-        hipLaunchKernelGGL(k2u_reads_kernel<kKW3115>, grid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
-                           n_reads, d_out, d_counts);
-    else
-        hipLaunchKernelGGL(k2u_reads_kernel<0>, grid, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets,
-                           n_reads, d_out, d_counts);
+        const bool per_item = v.front.lines != nullptr && !(rr && rr[0] == 'r');
+        if (per_item && grouped) MZ_LAUNCH_READS((k2u_reads_wave_kernel<true, true>), wgrid);
+        else if (per_item) MZ_LAUNCH_READS((k2u_reads_wave_kernel<true, false>), wgrid);
+        else if (grouped) MZ_LAUNCH_READS((k2u_reads_wave_kernel<false, true>), wgrid);
+        else MZ_LAUNCH_READS((k2u_reads_wave_kernel<false, false>), wgrid);
+    } else if (v.k == 31 && v.w == 15) {
+        MZ_LAUNCH_READS((k2u_reads_kernel<kKW3115>), grid);
+    } else {
+        MZ_LAUNCH_READS((k2u_reads_kernel<0>), grid);
+    }
+#undef MZ_LAUNCH_READS
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;
 }

@@ -121,10 +121,11 @@ def mutate_positions(us, positions):
     return us
 
 
-def build_index_unique(us, w, skew_param, seed=0, device=0, on_device=True, max_rounds=4, log=None):
+def build_index_unique(us, w, skew_param, seed=0, device=0, on_device=True, max_rounds=4, log=None, check=True):
     """build the SSHash of a synthetic unitig set and make its canonical k-mers unique: duplicates reported by the device
     validate_self (a few at GRCh38 scale: the birthday bound of random sequence) are broken up by substituting one base
-    in the middle of the later copy, and the index is rebuilt.  Returns (index, report, rounds)."""
+    in the middle of the later copy, and the index is rebuilt.  Returns (index, report, rounds).  check=False builds once and
+    validates nothing (stage-cost experiments with kernels whose results are meaningless)."""
     from . import kphf
     import numpy as np
     k = us["k"]
@@ -136,6 +137,8 @@ def build_index_unique(us, w, skew_param, seed=0, device=0, on_device=True, max_
               else kphf.SSHash.from_unitig_set(uset, w, skew_param, seed))
         del uset
         ix.to_device(device)
+        if not check:
+            return ix, None, 0
         rep, dups = ix.validate_self_duplicates()
         if log:
             log(f"validate_self round {rnd}: {rep}")
