@@ -416,7 +416,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "frac_own_layout": round(batch * B_ALG_OWN[bool(ix.has_minimizer_lines())] / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic_gbs": round(traffic / avg_kernel_s / 1e9, 1) if traffic else None,
-                         "kernel": {"v1": "k2u_batch_kernel", "tile": "k2u_tile_kernel"}.get(os.environ.get("MZ_K2U_KERNEL", ""), "k2u_wave_kernel"), "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
+                         "kernel": {3: "k2u_batch_kernel", 2: "k2u_tile_kernel"}.get(ix.get_query_opts()["point_kernel"], "k2u_wave_kernel"), "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_kmer": B_ALG},
             "build": {"gen_s": round(t_gen, 2), "where": "host" if args.host_build else "gpu", "build_and_validate_s": round(t_build, 2),
                       "rebuilds_for_duplicates": rebuilds, "bits_per_kmer": round(ix.num_bits() / ix.n_kmers(), 2)},

@@ -120,6 +120,35 @@ int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew
  * does not cover (w > 16, or an occurrence not fitting one 64-bit sort key) are built on the host transparently. */
 int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int device,
                                      mz_sshash **out);
+/* Construction with the layout choices that (w, skew_param) do not fix.  In the reference every construction parameter is an
+ * argument (SSHash::from_unitig_set / from_unitig_set_no_skew_index, sshash.rs:397-412; CLI minimizer_size / skew_min,
+ * bin/kphf/main.rs:75,178); the choices below are this library's own and never change a result.  Zero-initialise the struct,
+ * set struct_size = sizeof(mz_build_opts), set what you want to decide; 0 leaves a choice to the size rules.  opts == NULL is
+ * mz_sshash_from_unitig_set with all host threads. */
+typedef struct mz_build_opts {
+    uint32_t struct_size;
+    int32_t device;                 /* >= 0: heavy steps on that GPU, index left resident there (mz_sshash_from_unitig_set_device); < 0: host builder */
+    int32_t n_threads;              /* host threads; <= 0: all */
+    int32_t minimizer_lines;        /* 1: always build the minimizer lines (2w <= 32 only); -1: never; 0: when the table fits the size rule */
+    uint32_t lines_max_load;        /* mean bucket entries per 16-slot line the table may carry (sets g: 3 -> 34 GB, 10 -> 9 GB on a GRCh38-sized set); 0: 3, else 5, else 10 */
+    uint64_t direct_bytes_per_key;  /* budget of the direct-address minimizer records, bytes per distinct minimizer; 0: the rule of mz_sshash_minimizer_mphf_kind */
+} mz_build_opts;
+int mz_sshash_from_unitig_set_opts(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, const mz_build_opts *opts,
+                                   mz_sshash **out);
+/* Kernel choices of the query entry points of one index handle; none changes a result.  Same struct conventions; 0 = the rule.
+ * Set them before querying (they are read without a lock); opts == NULL restores the rules.  No counterpart in the reference
+ * (its k2u has one implementation); the environment variables of the repository's A/B tools only pre-set a new handle. */
+typedef struct mz_query_opts {
+    uint32_t struct_size;
+    int32_t point_kernel;  /* 1: wave-scoped tiles (the rule); 2: workgroup-scoped tiles; 3: one lane per query */
+    int32_t reads_lines;   /* reads resolve through 1: the minimizer lines; -1: the minimizer records; rule: lines from 2^28 bucket entries on */
+    int32_t reads_resolve; /* through the lines, 1: every window scans its line (the rule); 2: one lookup per run of windows */
+    int32_t reads_kernel;  /* 1: wave-scoped reads kernel (the rule at k = 31, w = 15); 2: workgroup-staged */
+    int32_t reads_verify;  /* 1: one sequence-record gather per candidate (the rule); 2: grouped verify-and-extend */
+    int32_t reads_grid;    /* workgroups per CU of the wave-scoped reads kernel; rule: 24 */
+} mz_query_opts;
+int mz_sshash_set_query_opts(mz_sshash *ix, const mz_query_opts *opts);
+int mz_sshash_get_query_opts(const mz_sshash *ix, mz_query_opts *opts);
 void mz_sshash_free(mz_sshash *ix);
 
 /* trait K2U accessors, kphf/mod.rs:58-67 (impl at sshash.rs:446-469) */
@@ -145,7 +174,7 @@ uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix);
 /* 1 when the index carries minimizer lines: membership and the entries of most buckets (sshash.rs:478-495: MPHF probe, two
  * Elias-Fano offsets, position array) answered by one 128-byte gather.  Built for direct-address minimizers when the table
  * (sized by the entries: at most 3, else 5, else 10 per line of 16 slots) stays within max(64 MiB, 64 bytes per entry,
- * min(9 GiB, 1 KiB per entry)); MZ_FRONT_TABLE=0 / 1 in the environment of the BUILD disables / forces it. */
+ * min(9 GiB, 1 KiB per entry)); mz_build_opts.minimizer_lines / lines_max_load decide otherwise. */
 uint32_t mz_sshash_has_minimizer_lines(const mz_sshash *ix);
 /* bytes resident in HBM once uploaded */
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix);
@@ -174,7 +203,11 @@ int mz_sshash_k2u_batch_compact_device(mz_sshash *ix, const uint64_t *d_fw_words
  * bases = concatenated ASCII reads, read_offsets = n_reads+1 byte offsets.  Window j of read r is
  * written to out[kmer_offsets[r] + j] where kmer_offsets is the prefix sum of max(0, len_r - k + 1);
  * out must hold kmer_offsets[n_reads] records (mz_reads_n_windows computes it).  `streaming` != 0
- * requests the .as_streaming() path (index/caching.rs:65-103); results are identical by contract. */
+ * requests the .as_streaming() path (index/caching.rs:65-103).  The batch path is the same either way -- every window gets
+ * the answer of its own k2u -- so the flag changes nothing here; that equals the reference's streaming walk for unitig
+ * sets whose canonical k-mers are unique (every cdBG).  On a set with repeated k-mers (UnitigSet::from_seqs on arbitrary
+ * strings) the reference's warm step stays on the previous unitig where an independent lookup may answer with another
+ * copy; mz_streaming_k2u keeps that state machine, one k-mer at a time. */
 uint64_t mz_reads_n_windows(const uint64_t *read_offsets, uint64_t n_reads, uint32_t k);
 int mz_sshash_k2u_reads(mz_sshash *ix, const uint8_t *bases, const uint64_t *read_offsets, uint64_t n_reads,
                         int streaming, mz_k2upos *out, mz_counts *counts);

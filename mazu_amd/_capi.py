@@ -27,6 +27,16 @@ class Counts(C.Structure):
     _fields_ = [("n_hit", C.c_uint64), ("n_miss", C.c_uint64), ("n_skipped", C.c_uint64)]
 
 
+class BuildOpts(C.Structure):  # mz_build_opts
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("n_threads", C.c_int32), ("minimizer_lines", C.c_int32),
+                ("lines_max_load", C.c_uint32), ("direct_bytes_per_key", C.c_uint64)]
+
+
+class QueryOpts(C.Structure):  # mz_query_opts
+    _fields_ = [("struct_size", C.c_uint32), ("point_kernel", C.c_int32), ("reads_lines", C.c_int32), ("reads_resolve", C.c_int32),
+                ("reads_kernel", C.c_int32), ("reads_verify", C.c_int32), ("reads_grid", C.c_int32)]
+
+
 class ValidateReport(C.Structure):
     _fields_ = [("n_kmers", C.c_uint64), ("n_fail", C.c_uint64), ("n_duplicate", C.c_uint64), ("first_fail_pos", C.c_uint64)]
 
@@ -61,6 +71,9 @@ def _load():
         "mz_unitig_set_useq_words": (p, [p]),
         "mz_sshash_from_unitig_set": (i, [p, u32, u64, u64, i, p]),
         "mz_sshash_from_unitig_set_device": (i, [p, u32, u64, u64, i, p]),
+        "mz_sshash_from_unitig_set_opts": (i, [p, u32, u64, u64, p, p]),
+        "mz_sshash_set_query_opts": (i, [p, p]),
+        "mz_sshash_get_query_opts": (i, [p, p]),
         "mz_sshash_free": (None, [p]),
         "mz_sshash_k": (u32, [p]),
         "mz_sshash_n_kmers": (u64, [p]),

@@ -401,7 +401,8 @@ bool gpu_build_supported(const UnitigSet &us, uint32_t w) {
 }
 
 // returns MZ_OK and fills `h` like SSHashHost::build, or MZ_EINVAL with last_error "unsupported" (caller falls back)
-int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device, DeviceIndex **keep) {
+int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device, DeviceIndex **keep, const BuildOpts &opts_) {
+    const BuildOpts opts = opts_.with_env();
     // keep != nullptr: the finished arrays stay in HBM as the replica *keep and are NOT copied to the host (h.arrays_on_host
     // == false; device_download() brings them over when somebody needs them there)
     if (keep) *keep = nullptr;
@@ -469,7 +470,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
     uint64_t n_mm = 0;
     BG_HIP(hipMemcpy(&n_mm, d_nsel, 8, hipMemcpyDeviceToHost));
     h.n_minimizers = n_mm;
-    if (!use_direct_records(w, n_mm)) { set_error("GPU build unsupported: host rule selects the BBHash minimizer MPHF"); return MZ_EINVAL; }
+    if (!use_direct_records(w, n_mm, opts)) { set_error("GPU build unsupported: host rule selects the BBHash minimizer MPHF"); return MZ_EINVAL; }
     // bucket starts: psum[i] = occurrences before minimizer i (n_mm + 1 values); run_start == psum in monotone mode
     uint64_t *d_psum = nullptr;
     BG_HIP(buf.alloc(&d_psum, n_mm + 1));
@@ -538,7 +539,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         }
         // minimizer lines from the finished records, bucket starts and entries
         h.front.lines.clear();
-        h.front.present = FrontTable::choose(w, n_occ, true, h.front.g, h.front.t);
+        h.front.present = FrontTable::choose(w, n_occ, true, opts, h.front.g, h.front.t);
         while (h.front.present) {
             const uint32_t line_bits = 2 * w - h.front.g - h.front.t;
             const uint64_t n_lines = 1ull << line_bits;
@@ -552,7 +553,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
             BG_HIP(hipMemcpy(&overfull, d_counter, 8, hipMemcpyDeviceToHost));
             if (overfull) { // some line has more than 16 member keys: fold the key space less (as the host builder does)
                 buf.release(d_lines);
-                h.front.present = FrontTable::next_shape(w, n_occ, h.front.g, h.front.t);
+                h.front.present = FrontTable::next_shape(w, n_occ, opts, h.front.g, h.front.t);
                 continue;
             }
             if (!resident) {

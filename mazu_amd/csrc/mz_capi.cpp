@@ -54,6 +54,7 @@ struct HostPipe {
 
 struct mz_sshash {
     SSHashHost host;
+    QueryOpts qopts = QueryOpts::from_env(); // kernel choices of the query entry points (mz_sshash_set_query_opts); read without a lock: set them before querying
     std::vector<HostPipe *> idle_pipes;   // guarded by mu
     DeviceIndex *dev = nullptr;           // default replica (first one placed, or the last mz_sshash_to_device target)
     std::vector<DeviceIndex *> replicas;  // one per device the index has been placed on (index replicated per GPU)
@@ -118,6 +119,16 @@ int mz_internal_default_device(mz_sshash *ix, int *device) {
     return rc;
 }
 
+// fields of a caller's struct that lie within the struct_size it states (a caller built against an older, shorter struct leaves the rest at 0 = rule)
+template <class T>
+static bool copy_opts(const T *src, T *dst, const char *what) {
+    *dst = T();
+    if (!src) return true;
+    if (src->struct_size < sizeof(uint32_t) || src->struct_size > 4096) { set_error("%s: struct_size %u is not a size of this struct", what, src->struct_size); return false; }
+    std::memcpy(dst, src, std::min<size_t>(src->struct_size, sizeof(T)));
+    dst->struct_size = (uint32_t)sizeof(T);
+    return true;
+}
 extern "C" {
 
 const char *mz_last_error(void) { return last_error(); }
@@ -154,15 +165,14 @@ uint64_t mz_unitig_set_pos_to_id(const mz_unitig_set *us, uint64_t pos) { return
 const uint64_t *mz_unitig_set_useq_words(const mz_unitig_set *us) { return us->us.useq.data(); }
 
 // ------------------------------------------------------------------- SSHash
-int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int n_threads,
-                              mz_sshash **out) {
+static int build_host(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int n_threads, const BuildOpts &bo, mz_sshash **out) {
     if (!us || !out) { set_error("null argument"); return MZ_EINVAL; }
     *out = nullptr;
     mz_sshash *ix = new (std::nothrow) mz_sshash();
     if (!ix) return MZ_ENOMEM;
     int rc;
     try {
-        rc = ix->host.build(us->us, w, skew_param, seed, n_threads);
+        rc = ix->host.build(us->us, w, skew_param, seed, n_threads, bo);
     } catch (const std::bad_alloc &) {
         set_error("out of host memory while building the index");
         rc = MZ_ENOMEM;
@@ -171,7 +181,44 @@ int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew
     *out = ix;
     return MZ_OK;
 }
+static int build_device(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int device, int n_threads, const BuildOpts &bo, mz_sshash **out);
+int mz_sshash_from_unitig_set(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int n_threads,
+                              mz_sshash **out) {
+    return build_host(us, w, skew_param, seed, n_threads, BuildOpts(), out);
+}
 int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int device, mz_sshash **out) {
+    return build_device(us, w, skew_param, seed, device, 0, BuildOpts(), out);
+}
+int mz_sshash_from_unitig_set_opts(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, const mz_build_opts *opts, mz_sshash **out) {
+    mz_build_opts o;
+    if (!copy_opts(opts, &o, "mz_build_opts")) return MZ_EINVAL;
+    if (o.minimizer_lines < -1 || o.minimizer_lines > 1) { set_error("mz_build_opts.minimizer_lines must be -1, 0 or 1"); return MZ_EINVAL; }
+    BuildOpts bo;
+    bo.minimizer_lines = o.minimizer_lines;
+    bo.lines_max_load = o.lines_max_load;
+    bo.direct_bytes_per_key = o.direct_bytes_per_key;
+    if (o.device >= 0 && opts) return build_device(us, w, skew_param, seed, o.device, o.n_threads, bo, out);
+    return build_host(us, w, skew_param, seed, o.n_threads, bo, out);
+}
+int mz_sshash_set_query_opts(mz_sshash *ix, const mz_query_opts *opts) {
+    if (!ix) { set_error("null index"); return MZ_EINVAL; }
+    mz_query_opts o;
+    if (!copy_opts(opts, &o, "mz_query_opts")) return MZ_EINVAL;
+    if (o.point_kernel < 0 || o.point_kernel > 3 || o.reads_lines < -1 || o.reads_lines > 1 || o.reads_resolve < 0 || o.reads_resolve > 2 || o.reads_kernel < 0 ||
+        o.reads_kernel > 2 || o.reads_verify < 0 || o.reads_verify > 2 || o.reads_grid < 0) { set_error("mz_query_opts: a field is out of its range"); return MZ_EINVAL; }
+    QueryOpts q;
+    q.point_kernel = o.point_kernel; q.reads_lines = o.reads_lines; q.reads_resolve = o.reads_resolve; q.reads_kernel = o.reads_kernel;
+    q.reads_verify = o.reads_verify; q.reads_grid = o.reads_grid;
+    ix->qopts = q;
+    return MZ_OK;
+}
+int mz_sshash_get_query_opts(const mz_sshash *ix, mz_query_opts *opts) {
+    if (!ix || !opts) { set_error("null argument"); return MZ_EINVAL; }
+    const QueryOpts &q = ix->qopts;
+    *opts = mz_query_opts{(uint32_t)sizeof(mz_query_opts), q.point_kernel, q.reads_lines, q.reads_resolve, q.reads_kernel, q.reads_verify, q.reads_grid};
+    return MZ_OK;
+}
+static int build_device(const mz_unitig_set *us, uint32_t w, uint64_t skew_param, uint64_t seed, int device, int n_threads, const BuildOpts &bo, mz_sshash **out) {
     DeviceGuard guard;
     if (!us || !out) { set_error("null argument"); return MZ_EINVAL; }
     *out = nullptr;
@@ -181,14 +228,14 @@ int mz_sshash_from_unitig_set_device(const mz_unitig_set *us, uint32_t w, uint64
     int rc = MZ_EINVAL;
     try {
         DeviceIndex *kept = nullptr; // the GPU builder leaves its arrays in HBM as the replica of `device`: no download, no second upload
-        if (gpu_build_supported(us->us, w)) rc = build_on_device(ix->host, us->us, w, skew_param, seed, device, &kept);
+        if (gpu_build_supported(us->us, w)) rc = build_on_device(ix->host, us->us, w, skew_param, seed, device, &kept, bo);
         if (rc == MZ_OK && kept) { ix->replicas.push_back(kept); ix->dev = kept; }
         if (rc == MZ_ENOMEM) { // the device ran out of memory next to what already lives there: the host builder can still do it
             std::fprintf(stderr, "[mazu_amd] GPU index build ran out of device memory (%s); building on the host instead\n", last_error());
             ix->host = SSHashHost();
             rc = MZ_EINVAL;
         }
-        if (rc == MZ_EINVAL) rc = ix->host.build(us->us, w, skew_param, seed, 0); // configuration left to the host builder
+        if (rc == MZ_EINVAL) rc = ix->host.build(us->us, w, skew_param, seed, n_threads, bo); // configuration left to the host builder
     } catch (const std::bad_alloc &) {
         set_error("out of host memory while building the index");
         rc = MZ_ENOMEM;
@@ -248,7 +295,7 @@ int mz_sshash_k2u_batch_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64
     DeviceIndex *r = nullptr;
     int rc = replica_for_pointer(ix, d_out, &r);
     if (rc != MZ_OK) return rc;
-    return launch_k2u_batch(*r, d_fw_words, n, d_out, d_counts, (hipStream_t)stream);
+    return launch_k2u_batch(*r, ix->qopts, d_fw_words, n, d_out, d_counts, (hipStream_t)stream);
 }
 
 int mz_sshash_k2u_batch_compact_device(mz_sshash *ix, const uint64_t *d_fw_words, uint64_t n, uint64_t *d_hit_idx,
@@ -460,7 +507,7 @@ int mz_sshash_k2u_batch(mz_sshash *ix, const uint64_t *fw_words, uint64_t n, mz_
             parallel_copy(p->h_in[slot], fw_words + b, len * 8, ct.stage);
             hipError_t e = hipMemcpyAsync(p->d_in[slot], p->h_in[slot], len * 8, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) {
-                const int r = launch_k2u_batch(*ix->dev, p->d_in[slot], len, p->d_out[slot], p->d_counts, st);
+                const int r = launch_k2u_batch(*ix->dev, ix->qopts, p->d_in[slot], len, p->d_out[slot], p->d_counts, st);
                 if (r != MZ_OK) return r;
                 e = hipMemcpyAsync(p->h_out[slot], p->d_out[slot], len * sizeof(mz_k2upos), hipMemcpyDeviceToHost, st);
             }
@@ -503,7 +550,7 @@ int mz_sshash_k2u_reads_device(mz_sshash *ix, const uint8_t *d_bases, uint64_t n
     DeviceIndex *r = nullptr;
     int rc = replica_for_pointer(ix, d_read_offsets, &r);
     if (rc != MZ_OK) return rc;
-    return launch_k2u_reads(*r, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, streaming, d_out, d_counts,
+    return launch_k2u_reads(*r, ix->qopts, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, streaming, d_out, d_counts,
                             (hipStream_t)stream);
 }
 
@@ -549,7 +596,7 @@ static int k2u_reads_pipelined(mz_sshash *ix, const uint8_t *bases, const uint64
             const uint8_t *d_b = reinterpret_cast<const uint8_t *>(d_ko + (nr + 1));
             hipError_t e = hipMemcpyAsync(p->d_in[slot], p->h_in[slot], in_bytes, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) {
-                const int r = launch_k2u_reads(*ix->dev, d_b, nb, d_ro, d_ko, nr, streaming, p->d_out[slot], p->d_counts, st);
+                const int r = launch_k2u_reads(*ix->dev, ix->qopts, d_b, nb, d_ro, d_ko, nr, streaming, p->d_out[slot], p->d_counts, st);
                 if (r != MZ_OK) return r;
                 if (n_win) e = hipMemcpyAsync(p->h_out[slot], p->d_out[slot], n_win * sizeof(mz_k2upos), hipMemcpyDeviceToHost, st);
             }
@@ -617,7 +664,7 @@ int mz_sshash_k2u_reads(mz_sshash *ix, const uint8_t *bases, const uint64_t *rea
         (e = hipMemcpyAsync(d_ro, ro.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s)) != hipSuccess ||
         (e = hipMemcpyAsync(d_ko, ko.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s)) != hipSuccess ||
         (e = hipMemsetAsync(d_c, 0, sizeof(mz_counts), s)) != hipSuccess) rc = MZ_EHIP;
-    if (rc == MZ_OK) rc = launch_k2u_reads(*ix->dev, d_b, n_bases, d_ro, d_ko, n_reads, streaming, d_o, d_c, s);
+    if (rc == MZ_OK) rc = launch_k2u_reads(*ix->dev, ix->qopts, d_b, n_bases, d_ro, d_ko, n_reads, streaming, d_o, d_c, s);
     if (rc == MZ_OK && n_win && (e = hipMemcpyAsync(out, d_o, n_win * sizeof(mz_k2upos), hipMemcpyDeviceToHost, s)) != hipSuccess) rc = MZ_EHIP;
     mz_counts hc{0, 0, 0};
     if (rc == MZ_OK && (e = hipMemcpyAsync(&hc, d_c, sizeof hc, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = MZ_EHIP;

@@ -1068,13 +1068,11 @@ __device__ __forceinline__ uint32_t tile_finish_grouped(TileLdsT<SC::NT> &S, con
     static_assert(offsetof(Lds, eoff) == offsetof(Lds, n) + sizeof(uint32_t) * 64 * kQpt && offsetof(Lds, n) % 16 == 0 && sizeof(uint32_t) * (2 * 64 * kQpt + 1) >= 2048 &&
                       (kStashWords * 8) % 16 == 0, "stash slots in n[] + eoff[]");
     const uint32_t lane = SC::tid(), k = ix.k;
-    const unsigned long long lt_mask = (1ull << lane) - 1, le_mask = lt_mask | (1ull << lane);
     constexpr uint64_t kPosMask = (1ull << kPosBits) - 1;
     constexpr uint32_t kTileBases = 32 * kAlignTileWords, kNoSlot = ~0u;
     MZ_MARK("FIN_A");
-    uint32_t sidx[kQpt];                                          // stash slot (number of the group) of my window's candidate; kNoSlot: none
-    uint32_t n_lead = 0, carry_a = ~0u, carry_b = 0, carry_slot = 0; // uniform; key and group of the latest candidate of the rows before
-    bool any_unk = false;
+    uint32_t sidx[kQpt];            // stash slot (number of the group) of my window's candidate; kNoSlot: none
+    uint32_t n_lead = 0, carry_a = ~0u, carry_b = 0; // uniform; groups so far, key of the last window of the row before
 #pragma unroll
     for (int q = 0; q < kQpt; ++q) {
         const uint32_t i = q * 64 + lane;
@@ -1083,26 +1081,21 @@ __device__ __forceinline__ uint32_t tile_finish_grouped(TileLdsT<SC::NT> &S, con
         const uint64_t p = b & kPosMask;
         uint32_t off;
         // key: record | orientation << 30 | unknown << 31 (records are < 2^30), and the low half of the diagonal (two candidates in
-        // one record lie fewer than 128 positions apart, so equal low halves are equal diagonals)
+        // one record lie fewer than 128 positions apart, so equal low halves are equal diagonals).  A window joins the group of the
+        // window before it when the keys agree (a window without a candidate has a key of its own and ends a group).
         const uint32_t ka = has ? (uint32_t)seq_rec_of(p, off) | (twin ? 1u << 30 : 0u) | (unk ? 1u << 31 : 0u) : ~0u;
         const uint32_t kb = twin ? (uint32_t)p + i : (uint32_t)p - i;
-        const unsigned long long has_b = __ballot(has), before = has_b & lt_mask;
-        const uint32_t src = before ? 63u - (uint32_t)__clzll(before) : lane;        // nearest earlier window with a candidate
-        uint32_t pa = (uint32_t)__shfl((int)ka, (int)src), pb = (uint32_t)__shfl((int)kb, (int)src);
-        if (!before) { pa = carry_a; pb = carry_b; }
+        uint32_t pa = wave_prev(ka), pb = wave_prev(kb);
+        if (lane == 0) { pa = carry_a; pb = carry_b; }
         const bool lead = has && (pa != ka || pb != kb || unk);
-        const unsigned long long lead_b = __ballot(lead), mine = lead_b & le_mask;
-        const uint32_t slot = mine ? n_lead + (uint32_t)__popcll(mine) - 1u : carry_slot; // the candidates between a leader and me continue its group
+        const unsigned long long lead_b = __ballot(lead);
+        // leaders at or before me in this row; with none, the group that came over from the row before is the latest one
+        const uint32_t slot = n_lead + __builtin_amdgcn_mbcnt_hi((uint32_t)(lead_b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lead_b, 0u)) + (lead ? 1u : 0u) - 1u;
         sidx[q] = has ? slot : kNoSlot;
-        if (lead) S.list_a[n_lead + (uint32_t)__popcll(lead_b & lt_mask)] = (typename Lds::ListT)i;
-        if (has_b) {
-            const int lastl = 63 - __clzll(has_b);
-            carry_a = (uint32_t)__builtin_amdgcn_readlane((int)ka, lastl);
-            carry_b = (uint32_t)__builtin_amdgcn_readlane((int)kb, lastl);
-            carry_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, lastl);
-        }
+        if (lead) S.list_a[slot] = (typename Lds::ListT)i;
+        carry_a = (uint32_t)__builtin_amdgcn_readlane((int)ka, 63);
+        carry_b = (uint32_t)__builtin_amdgcn_readlane((int)kb, 63);
         n_lead += (uint32_t)__popcll(lead_b);
-        any_unk = any_unk || __ballot(unk) != 0;
     }
     MZ_MARK("FIN_A_END");
     SC::sync();
@@ -1120,17 +1113,21 @@ __device__ __forceinline__ uint32_t tile_finish_grouped(TileLdsT<SC::NT> &S, con
             const uint64_t p = (b & kPosMask) <= ix.total_len - k ? b & kPosMask : 0ull; // (a candidate is always a k-mer position of the sequence; never trust a gather address blindly)
             uint32_t off;
             const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(ix.seqbv + seq_rec_of(p, off) * kSeqRecWords); // idle lanes re-read the first leader's record
-            const ulonglong2 r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
-            // the tile's bases along the diagonal: record base y <-> aligned position a0 + y
+            // the tile's bases along the diagonal: record base y <-> aligned position a0 + y (taken from LDS before the record is requested:
+            // fewer registers are live while the loads are in flight)
             const bool twin = (b & kBestTwin) != 0;
             const uint32_t a0 = twin ? 32 * kAlignRcAt + (kTileBases - item - k) - off : 32 * kAlignPad + item - off; // in bases from word 0 of `aligned`
             const uint32_t W = a0 >> 5, sh = 2 * (a0 & 31);
-            uint64_t A[5], X[4];
+            uint64_t X[4];
+            {
+                uint64_t A[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) A[j] = aligned[W + j];
-            const uint64_t raw = (b & kBestUnk) ? 0ull : ~0ull;
+                for (int j = 0; j < 5; ++j) A[j] = aligned[W + j];
+                const uint64_t raw = (b & kBestUnk) ? 0ull : ~0ull;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) X[j] = ((A[j] >> sh) | ((A[j + 1] << 1) << (63 - sh))) & raw;
+                for (int j = 0; j < 4; ++j) X[j] = ((A[j] >> sh) | ((A[j + 1] << 1) << (63 - sh))) & raw;
+            }
+            const ulonglong2 r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
             // boundary tables of the quarters 0..2 (a window starts in the first 96 bases of its record)
             const uint32_t q0 = (uint32_t)r3.x, q1 = (uint32_t)(r3.x >> 32), q2 = (uint32_t)r3.y, q3 = (uint32_t)(r3.y >> 32);
             const uint32_t c1 = (uint32_t)__popc(q0), c2 = c1 + (uint32_t)__popc(q1);
@@ -1162,7 +1159,7 @@ __device__ __forceinline__ uint32_t tile_finish_grouped(TileLdsT<SC::NT> &S, con
             const uint64_t lo = st[wi], hi = st[wi + 1];
             const uint64_t x = ((lo >> sh) | ((hi << 1) << (63 - sh))) & kmer_mask(k);
             uint32_t mt = x == 0 ? ((b & kBestTwin) ? MZ_TWIN_MATCH : MZ_IDENTITY_MATCH) : MZ_NO_MATCH;
-            if (any_unk) { // (uniform) a skew-table candidate says nothing about its orientation: compare words
+            if (__ballot((b & kBestUnk) != 0)) { // (uniform, rows with heavy windows only) a skew-table candidate says nothing about its orientation: compare words
                 const uint32_t ti = 32 * kAlignPad + i, tw = ti >> 5, ts = 2 * (ti & 31);
                 const uint64_t fw = ((aligned[tw] >> ts) | ((aligned[tw + 1] << 1) << (63 - ts))) & kmer_mask(k);
                 if (b & kBestUnk) mt = word_equivalency(fw, kmer_rc(fw, k), x);
@@ -2146,16 +2143,7 @@ static unsigned grid_for(const DeviceIndex &d, uint64_t n_items, unsigned blocks
     return (unsigned)std::max<uint64_t>(1, std::min(need, cap));
 }
 
-static bool use_v1_kernel() {
-    static const bool v = [] { const char *e = getenv("MZ_K2U_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
-    return v;
-}
-static bool use_wave_kernel() {
-    static const bool v = [] { const char *e = getenv("MZ_K2U_KERNEL"); return !e || e[0] != 't'; }(); // default; MZ_K2U_KERNEL=tile selects the workgroup-scoped form
-    return v;
-}
-
-int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
+int launch_k2u_batch(const DeviceIndex &d, const QueryOpts &opts, const uint64_t *d_fw, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
                      hipStream_t stream) {
     if (n == 0) return MZ_OK;
     MZ_HIP_CHECK(hipSetDevice(d.device));
@@ -2163,19 +2151,18 @@ int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_
         set_error("unitig set longer than 2^%u bases is not supported by the tile kernel", kPosBits);
         return MZ_EINVAL;
     }
-    if (use_v1_kernel()) { // lane-per-query kernel (kept for A/B measurements)
+    if (opts.point_kernel == 3) { // lane-per-query kernel (kept for A/B measurements)
         hipLaunchKernelGGL(k2u_batch_kernel, dim3(grid_for(d, n, 32)), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
-    } else if (use_wave_kernel()) {
+    } else if (opts.point_kernel != 2) {
         uint64_t n_blocks = (n + kTileQ - 1) / kTileQ; // four 256-query wave tiles per workgroup
         unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_blocks, (uint64_t)d.n_cu * 4096));
         if (d.view.k == 31 && d.view.w == 15)
             hipLaunchKernelGGL(k2u_wave_kernel<kKW3115>, dim3(grid), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
         else
             hipLaunchKernelGGL(k2u_wave_kernel<0>, dim3(grid), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
-    } else {
+    } else { // workgroup-scoped tiles, one tile per workgroup (4 .. 1000 tiles per workgroup measured 10.5 .. 11.0 G/s when this was the default)
         uint64_t n_tiles = (n + kTileQ - 1) / kTileQ;
-        static const unsigned gf = [] { const char *e = getenv("MZ_GRID_FACTOR"); int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 4096); }(); // one tile per workgroup measured best (gf 4..1000: 10.5..11.0 G/s)
-        unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)d.n_cu * gf));
+        unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)d.n_cu * 4096));
         if (d.view.k == 31 && d.view.w == 15)
             hipLaunchKernelGGL(k2u_tile_kernel<kKW3115>, dim3(grid), dim3(kBlock), 0, stream, d.view, d_fw, n, d_out, d_counts);
         else
@@ -2199,36 +2186,31 @@ int launch_k2u_compact(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, u
     return MZ_OK;
 }
 
-int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
+int launch_k2u_reads(const DeviceIndex &d, const QueryOpts &opts, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
                      const uint64_t *d_kmer_offsets, uint64_t n_reads, int streaming, mz_k2upos *d_out,
                      mz_counts *d_counts, hipStream_t stream) {
     if (n_bases == 0 || n_reads == 0) return MZ_OK;
     MZ_HIP_CHECK(hipSetDevice(d.device));
     const dim3 grid(tile_grid(d, (n_bases + kTileQ - 1) / kTileQ, 8));
-    (void)streaming; // same kernel: see the note above k2u_reads_kernel
+    (void)streaming; // same kernels: a streaming request changes nothing (see the note above k2u_reads_kernel)
     // The windows of a read share their minimizer for ~9 positions, and the windows of one strand class form runs of ~4.6.
     // Small indexes: one lookup per run through the minimizer records, the run's bucket then scanned by each of its windows
     // (stage S3).  Large indexes (2^28 bucket entries and more): through the minimizer lines, and there every window scans
     // its line itself as a point query does (stage SF: the flank test of all 16 slots costs a window less than S3 costs it
     // when buckets hold several entries, 4.5 per window on the GRCh38-shaped set; the line comes from the caches for all
     // but the first window of a run).  Measured in G windows/s, run / item: s-txome (60 M entries, lines forced) 31.2 / 28.5,
-    // records 32.1; S-human (547 M) 21.2 / 23.4; s-pan (1.2 G) 15.9 / 19.3.  MZ_READS_LINES=0/1 and MZ_READS_RESOLVE=run/item override.
+    // records 32.1; S-human (547 M) 21.2 / 23.4; s-pan (1.2 G) 15.9 / 19.3.  QueryOpts::reads_lines / reads_resolve override.
     IndexView v = d.view;
-    const char *lines_env = getenv("MZ_READS_LINES");
-    const bool use_lines = lines_env ? lines_env[0] != '0' : d.n_entries >= (1ull << 28);
+    const bool use_lines = opts.reads_lines ? opts.reads_lines > 0 : d.n_entries >= (1ull << 28);
     if (!use_lines && v.mm.direct) v.front.lines = nullptr;
-    const char *rk = getenv("MZ_READS_KERNEL"); // "block": the workgroup-staged kernel also for (31, 15)
-    const char *vf = getenv("MZ_READS_VERIFY"); // "each": one sequence-record gather per candidate (stage S5) instead of one per group of windows
-    const bool grouped = !(vf && vf[0] == 'e');
+    const bool grouped = opts.reads_verify == 2; // grouped verify-and-extend (tile_finish_grouped) instead of one sequence-record gather per candidate
 #define MZ_LAUNCH_READS(KERNEL, GRID) hipLaunchKernelGGL(KERNEL, GRID, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts)
-    if (v.k == 31 && v.w == 15 && !(rk && rk[0] == 'b')) {
+    if (v.k == 31 && v.w == 15 && opts.reads_kernel != 2) {
         const uint64_t n_wave_tiles = (n_bases + kWaveTile - 1) / kWaveTile;
         // workgroups per CU: 3 are resident; 24 give every slot eight shorter runs of tiles to even the finish out (measured 3: 31.0, 8: 30.3 --
         // 2.67 rounds --, 24: 31.7, 96: 30.7 G windows/s on s-txome; every wave starts with a search for its first read)
-        const char *ge = getenv("MZ_READS_GRID");
-        const dim3 wgrid(tile_grid(d, (n_wave_tiles + kBlock / 64 - 1) / (kBlock / 64), ge && atoi(ge) > 0 ? (unsigned)atoi(ge) : 24u));
-        const char *rr = getenv("MZ_READS_RESOLVE");
-        const bool per_item = v.front.lines != nullptr && !(rr && rr[0] == 'r');
+        const dim3 wgrid(tile_grid(d, (n_wave_tiles + kBlock / 64 - 1) / (kBlock / 64), opts.reads_grid > 0 ? (unsigned)opts.reads_grid : 24u));
+        const bool per_item = v.front.lines != nullptr && opts.reads_resolve != 2;
         if (per_item && grouped) MZ_LAUNCH_READS((k2u_reads_wave_kernel<true, true>), wgrid);
         else if (per_item) MZ_LAUNCH_READS((k2u_reads_wave_kernel<true, false>), wgrid);
         else if (grouped) MZ_LAUNCH_READS((k2u_reads_wave_kernel<false, true>), wgrid);

@@ -35,11 +35,11 @@ int device_upload(const SSHashHost &h, int device, DeviceIndex **out);
 void device_free(DeviceIndex *d);
 
 // all launchers are asynchronous on `stream`; pointers are device pointers on d.device
-int launch_k2u_batch(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
+int launch_k2u_batch(const DeviceIndex &d, const QueryOpts &opts, const uint64_t *d_fw, uint64_t n, mz_k2upos *d_out, mz_counts *d_counts,
                      hipStream_t stream);
 int launch_k2u_compact(const DeviceIndex &d, const uint64_t *d_fw, uint64_t n, uint64_t *d_hit_idx, mz_k2upos *d_hits,
                        uint64_t *d_n_hits, hipStream_t stream);
-int launch_k2u_reads(const DeviceIndex &d, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
+int launch_k2u_reads(const DeviceIndex &d, const QueryOpts &opts, const uint8_t *d_bases, uint64_t n_bases, const uint64_t *d_read_offsets,
                      const uint64_t *d_kmer_offsets, uint64_t n_reads, int streaming, mz_k2upos *d_out,
                      mz_counts *d_counts, hipStream_t stream);
 // d_report: 5 x u64 {n_kmers, n_fail, n_duplicate, first_fail_pos, n_listed}; caller initialises {0,0,0,~0,0}.
@@ -51,7 +51,8 @@ int launch_extract_kmers(const DeviceIndex &d, const uint64_t *d_positions, cons
 // index construction on the device (mz_build_gpu.hip); false / MZ_EINVAL when the configuration needs the host builder
 bool gpu_build_supported(const UnitigSet &us, uint32_t w);
 // keep != nullptr: the arrays stay in HBM as the replica *keep and h.arrays_on_host is false (see device_download)
-int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device, DeviceIndex **keep = nullptr);
+int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_t skew_param, uint64_t seed, int device, DeviceIndex **keep = nullptr,
+                    const BuildOpts &opts = BuildOpts());
 // copies the index arrays of a replica into the (empty) host vectors of `h`; afterwards h.arrays_on_host is true
 int device_download(const DeviceIndex &d, SSHashHost &h);
 

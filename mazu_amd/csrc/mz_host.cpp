@@ -661,12 +661,32 @@ static void scan_unitig(const uint64_t *useq, uint64_t s, uint64_t e, uint32_t k
 // table stays within max(64 MiB, 48 bytes per key, min(1 GiB, 1 KiB per key)).  The last term spends up to 1 GiB of the
 // 288 GB on sets of half a million minimizers and more (a yeast-sized set at w = 15: 0.54 GB of records, 25.0 against
 // 18.4 G k-mers/s through the BBHash levels); MZ_DIRECT_BYTES_PER_KEY replaces the rule by "at most that many bytes per key".
-bool use_direct_records(uint32_t w, uint64_t n_mm) {
+bool use_direct_records(uint32_t w, uint64_t n_mm, const BuildOpts &opts) {
     if (2 * w > 32) return false;
     const uint64_t rec_bytes = (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords * 8;
-    if (const char *e = getenv("MZ_DIRECT_BYTES_PER_KEY")) return rec_bytes <= std::max<uint64_t>(64ull << 20, strtoull(e, nullptr, 10) * n_mm);
+    if (opts.direct_bytes_per_key) return rec_bytes <= std::max<uint64_t>(64ull << 20, opts.direct_bytes_per_key * n_mm);
     const uint64_t free_cap = std::min<uint64_t>(1ull << 30, 1024 * n_mm);
     return rec_bytes <= std::max<uint64_t>(std::max<uint64_t>(64ull << 20, 48 * n_mm), free_cap);
+}
+BuildOpts BuildOpts::with_env() const {
+    BuildOpts o = *this;
+    if (o.minimizer_lines == 0)
+        if (const char *e = std::getenv("MZ_FRONT_TABLE")) o.minimizer_lines = e[0] == '1' ? 1 : e[0] == '0' ? -1 : 0;
+    if (o.lines_max_load == 0)
+        if (const char *e = std::getenv("MZ_FRONT_MAX_LOAD")) { const double v = std::atof(e); if (v >= 1) o.lines_max_load = (uint32_t)v; }
+    if (o.direct_bytes_per_key == 0)
+        if (const char *e = std::getenv("MZ_DIRECT_BYTES_PER_KEY")) o.direct_bytes_per_key = strtoull(e, nullptr, 10);
+    return o;
+}
+QueryOpts QueryOpts::from_env() {
+    QueryOpts o;
+    if (const char *e = std::getenv("MZ_K2U_KERNEL")) o.point_kernel = e[0] == 't' ? 2 : (e[0] == 'v' && e[1] == '1') ? 3 : 0;
+    if (const char *e = std::getenv("MZ_READS_LINES")) o.reads_lines = e[0] == '0' ? -1 : 1;
+    if (const char *e = std::getenv("MZ_READS_RESOLVE")) o.reads_resolve = e[0] == 'r' ? 2 : e[0] == 'i' ? 1 : 0;
+    if (const char *e = std::getenv("MZ_READS_KERNEL")) o.reads_kernel = e[0] == 'b' ? 2 : e[0] == 'w' ? 1 : 0;
+    if (const char *e = std::getenv("MZ_READS_VERIFY")) o.reads_verify = e[0] == 'g' ? 2 : e[0] == 'e' ? 1 : 0;
+    if (const char *e = std::getenv("MZ_READS_GRID")) { const int v = std::atoi(e); if (v > 0) o.reads_grid = v; }
+    return o;
 }
 uint32_t skew_fp_bits_for_build() {
     if (const char *e = std::getenv("MZ_TEST_SKEW_FP_BITS")) {
@@ -715,30 +735,24 @@ void SkewTable::build(const uint64_t *words, const uint64_t *pos, uint64_t n, in
     n_ovf = ovf_word.size();
 }
 
-static bool front_forced() { const char *e = std::getenv("MZ_FRONT_TABLE"); return e && e[0] == '1'; }
-
-bool FrontTable::choose(uint32_t w, uint64_t n_occ, bool direct, uint32_t &g, uint32_t &t) {
+bool FrontTable::choose(uint32_t w, uint64_t n_occ, bool direct, const BuildOpts &opts, uint32_t &g, uint32_t &t) {
     if (!direct || 2 * w > 32) return false; // the lines are addressed by key and built from the minimizer records
-    const char *e = std::getenv("MZ_FRONT_TABLE");
-    if (e && e[0] == '0') return false;
-    if (front_forced()) return front_shape_for_load(w, n_occ, 10, g, t); // whatever the table size
-    if (const char *l = std::getenv("MZ_FRONT_MAX_LOAD")) { // experiments: mean slots per line allowed (front_choose_shape prefers 3 and accepts 5 or 10)
-        const double load = std::atof(l);
-        if (load >= 1) return front_shape_for_load(w, n_occ, (uint64_t)load, g, t);
-    }
+    if (opts.minimizer_lines < 0) return false;
+    if (opts.lines_max_load >= 1) return front_shape_for_load(w, n_occ, opts.lines_max_load, g, t);
+    if (opts.minimizer_lines > 0) return front_shape_for_load(w, n_occ, 10, g, t); // whatever the table size
     return front_choose_shape(w, n_occ, g, t);
 }
 
-bool FrontTable::next_shape(uint32_t w, uint64_t n_occ, uint32_t &g, uint32_t &t) {
+bool FrontTable::next_shape(uint32_t w, uint64_t n_occ, const BuildOpts &opts, uint32_t &g, uint32_t &t) {
     if (t == 0) return false; // cannot happen: at most 2^g <= 16 keys share a line
     --t;
-    return front_forced() || (1ull << (2 * w - g - t)) * kFrontSlots * 8 <= front_table_cap(n_occ);
+    return opts.minimizer_lines > 0 || (1ull << (2 * w - g - t)) * kFrontSlots * 8 <= front_table_cap(n_occ);
 }
 
 void FrontTable::build(const uint64_t *minrec, uint32_t w, uint64_t n_occ, bool direct, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param,
-                       int n_threads) {
+                       int n_threads, const BuildOpts &opts) {
     lines.clear();
-    present = choose(w, n_occ, direct, g, t);
+    present = choose(w, n_occ, direct, opts, g, t);
     while (present) {
         const uint32_t line_bits = 2 * w - g - t;
         const uint64_t n_lines = 1ull << line_bits;
@@ -754,13 +768,14 @@ void FrontTable::build(const uint64_t *minrec, uint32_t w, uint64_t n_occ, bool 
         bool overfull = false;
         for (uint8_t x : bad) overfull = overfull || x;
         if (!overfull) return;
-        present = next_shape(w, n_occ, g, t); // some line has more than 16 member keys: fold the key space less
+        present = next_shape(w, n_occ, opts, g, t); // some line has more than 16 member keys: fold the key space less
     }
     lines.clear();
     g = t = 0;
 }
 
-int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads) {
+int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads, const BuildOpts &opts_) {
+    const BuildOpts opts = opts_.with_env();
     double t0 = now_s();
     const bool timing = std::getenv("MZ_BUILD_TIMING") != nullptr;
     double tp = t0;
@@ -833,7 +848,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     // 3. MPHF over the minimizer set, gamma = 1.7 (sshash.rs:177)
     // 2w <= 32: direct-address monotone MPHF (one line per probe, exact membership); else BBHash levels
     //   (only while the records stay small next to the key set: use_direct_records())
-    const bool use_direct = use_direct_records(w, n_mm);
+    const bool use_direct = use_direct_records(w, n_mm, opts);
     int rc = use_direct ? mm.build_direct(mm_set.data(), n_mm, 2 * w, nt) : mm.build(mm_set.data(), n_mm, 1.7, nt);
     if (rc != MZ_OK) return rc;
     phase("minimizer mphf");
@@ -922,7 +937,7 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     }
     pos.assign(posv.data(), n_occ, max_pos, nt);
     phase("EF + minrec + pack");
-    front.build(mm.blocks.data(), w, n_occ, mm.direct != 0, psum.data(), posv.data(), skew_param, nt);
+    front.build(mm.blocks.data(), w, n_occ, mm.direct != 0, psum.data(), posv.data(), skew_param, nt, opts);
     phase("minimizer lines");
     build_seconds = now_s() - t0;
     return MZ_OK;

@@ -13,6 +13,28 @@ namespace mz {
 
 int hw_threads();
 
+// Layout choices of a build that are not part of the reference's (w, skew_param, seed): arguments of
+// mz_sshash_from_unitig_set_opts.  0 = decide by the size rules below.  The environment variables MZ_FRONT_TABLE (0 / 1),
+// MZ_FRONT_MAX_LOAD and MZ_DIRECT_BYTES_PER_KEY of the A/B tools fill the fields a caller left at 0 (with_env, once per build).
+struct BuildOpts {
+    int minimizer_lines = 0;           // 1: always build the minimizer lines (2w <= 32), -1: never, 0: by the size rule
+    uint32_t lines_max_load = 0;       // mean entries per line of 16 slots the table may carry; 0: 3, else 5, else 10 (front_choose_shape)
+    uint64_t direct_bytes_per_key = 0; // the direct-address minimizer records may take this many bytes per minimizer; 0: the rule of use_direct_records
+    BuildOpts with_env() const;
+};
+// Kernel choices of the query entry points that do not change results: arguments of mz_sshash_set_query_opts, kept per index
+// handle.  0 = decide by the rules in launch_k2u_batch / launch_k2u_reads.  The A/B tools' MZ_K2U_KERNEL, MZ_READS_LINES,
+// MZ_READS_RESOLVE, MZ_READS_KERNEL, MZ_READS_VERIFY and MZ_READS_GRID fill a NEW handle's fields (from_env, once per handle).
+struct QueryOpts {
+    int point_kernel = 0;  // 1: wave-scoped tiles (the rule), 2: workgroup-scoped tiles, 3: one lane per query
+    int reads_lines = 0;   // reads resolve through 1: the minimizer lines, -1: the minimizer records; rule: lines from 2^28 bucket entries on
+    int reads_resolve = 0; // through the lines, 1: every window scans its line (the rule), 2: one lookup per run of windows
+    int reads_kernel = 0;  // 1: wave-scoped (the rule at k = 31, w = 15), 2: workgroup-staged
+    int reads_verify = 0;  // 1: one sequence-record gather per candidate (the rule), 2: grouped verify-and-extend (wave-scoped kernel)
+    int reads_grid = 0;    // workgroups per CU of the wave-scoped reads kernel; rule: 24
+    static QueryOpts from_env();
+};
+
 // fixed-width packed integers (the reference's IntVector::pack, sshash.rs:314-315)
 struct PackedVec {
     std::vector<uint64_t> w; // padded with 2 words
@@ -110,12 +132,13 @@ struct FrontTable {
     std::vector<uint64_t> lines;
     uint32_t g = 0, t = 0;
     bool present = false;
-    // shape of the table for this index, false when none is built.  MZ_FRONT_TABLE=0 never builds the lines, =1 builds them
-    // at a load of at most 10 whatever the table size, otherwise front_choose_shape decides; MZ_FRONT_MAX_LOAD sets the load
-    static bool choose(uint32_t w, uint64_t n_occ, bool direct, uint32_t &g, uint32_t &t);
+    // shape of the table for this index, false when none is built.  opts.minimizer_lines -1 never builds the lines, 1 builds them
+    // at a load of at most 10 whatever the table size, otherwise front_choose_shape decides; opts.lines_max_load sets the load
+    static bool choose(uint32_t w, uint64_t n_occ, bool direct, const BuildOpts &opts, uint32_t &g, uint32_t &t);
     // after a table turned out to have a line with more than 16 member keys: the next shape to try (half the tag), false when there is none
-    static bool next_shape(uint32_t w, uint64_t n_occ, uint32_t &g, uint32_t &t);
-    void build(const uint64_t *minrec, uint32_t w, uint64_t n_occ, bool direct, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads);
+    static bool next_shape(uint32_t w, uint64_t n_occ, const BuildOpts &opts, uint32_t &g, uint32_t &t);
+    void build(const uint64_t *minrec, uint32_t w, uint64_t n_occ, bool direct, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads,
+               const BuildOpts &opts);
     FrontView view() const { return present ? FrontView{lines.data(), (uint64_t)lines.size() / kFrontSlots, g, t} : FrontView{nullptr, 0, 0, 0}; }
     uint64_t n_words(uint32_t w) const { return present ? (1ull << (2 * w - g - t)) * kFrontSlots : 0; }
 };
@@ -141,7 +164,7 @@ struct SSHashHost {
     uint64_t n_bucket_block_words() const { return (((buckets.n - 1) >> kBefShift) + 1) * 8; }
     uint64_t n_bucket_ovf_words() const { return buckets.n_overflow ? buckets.n_overflow * (kBefSpan + 1) : 2; }
 
-    int build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads);
+    int build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads, const BuildOpts &opts = BuildOpts());
     IndexView view() const;
     uint64_t num_bits() const;
     int save(const std::string &path) const;
@@ -152,9 +175,9 @@ struct SSHashHost {
 // tests that need fingerprint collisions to be common)
 uint32_t skew_fp_bits_for_build();
 // minimizer MPHF kind: direct-address records while 2w <= 32 and they stay small next to the key set: at most
-// max(64 MiB, B bytes per key), B = 48 unless MZ_DIRECT_BYTES_PER_KEY says otherwise (a transcriptome-sized set at w = 15 then
+// max(64 MiB, B bytes per key), B = 48 unless opts.direct_bytes_per_key says otherwise (a transcriptome-sized set at w = 15 then
 // takes the records: one gather instead of the level loop, 1.6x the index, 1.9x the point-query rate); else BBHash levels
-bool use_direct_records(uint32_t w, uint64_t n_mm);
+bool use_direct_records(uint32_t w, uint64_t n_mm, const BuildOpts &opts);
 
 void set_error(const char *fmt, ...);
 const char *last_error();

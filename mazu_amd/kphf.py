@@ -163,6 +163,36 @@ class SSHash:  # sshash.rs:39-51
         return cls(h)
 
     @classmethod
+    def from_unitig_set_opts(cls, unitigs, w, skew_param, seed=0, device=-1, n_threads=0, minimizer_lines=0, lines_max_load=0, direct_bytes_per_key=0):
+        """construction with the layout choices of mz_build_opts (0 = the size rules); device >= 0 builds on that GPU"""
+        o = _capi.BuildOpts(C.sizeof(_capi.BuildOpts), device, n_threads, minimizer_lines, lines_max_load, direct_bytes_per_key)
+        h = C.c_void_p()
+        check(lib.mz_sshash_from_unitig_set_opts(unitigs._h, w, int(skew_param), int(seed), C.byref(o), C.byref(h)))
+        return cls(h)
+
+    POINT_KERNEL = {"wave": 1, "tile": 2, "lane": 3}
+    READS_LINES = {"lines": 1, "records": -1}
+    READS_RESOLVE = {"item": 1, "run": 2}
+    READS_KERNEL = {"wave": 1, "block": 2}
+    READS_VERIFY = {"each": 1, "group": 2}
+
+    def set_query_opts(self, point_kernel=None, reads_lines=None, reads_resolve=None, reads_kernel=None, reads_verify=None, reads_grid=0):
+        """kernel choices of this handle's query entry points (mz_query_opts); None = the rule.  Results never change."""
+        o = _capi.QueryOpts(C.sizeof(_capi.QueryOpts), self.POINT_KERNEL.get(point_kernel, 0), self.READS_LINES.get(reads_lines, 0),
+                            self.READS_RESOLVE.get(reads_resolve, 0), self.READS_KERNEL.get(reads_kernel, 0), self.READS_VERIFY.get(reads_verify, 0), reads_grid)
+        for name, val, table in (("point_kernel", point_kernel, self.POINT_KERNEL), ("reads_lines", reads_lines, self.READS_LINES),
+                                 ("reads_resolve", reads_resolve, self.READS_RESOLVE), ("reads_kernel", reads_kernel, self.READS_KERNEL),
+                                 ("reads_verify", reads_verify, self.READS_VERIFY)):
+            if val is not None and val not in table:
+                raise ValueError(f"{name}={val!r}: one of {sorted(table)}")
+        check(lib.mz_sshash_set_query_opts(self._h, C.byref(o)))
+
+    def get_query_opts(self):
+        o = _capi.QueryOpts()
+        check(lib.mz_sshash_get_query_opts(self._h, C.byref(o)))
+        return {f: getattr(o, f) for f, _ in _capi.QueryOpts._fields_ if f != "struct_size"}
+
+    @classmethod
     def from_unitig_set_no_skew_index(cls, unitigs, w, seed=0, n_threads=0):  # sshash.rs:397-403
         return cls.from_unitig_set(unitigs, w, MZ_NO_SKEW_INDEX, seed, n_threads)
 

@@ -121,11 +121,12 @@ def mutate_positions(us, positions):
     return us
 
 
-def build_index_unique(us, w, skew_param, seed=0, device=0, on_device=True, max_rounds=4, log=None, check=True):
+def build_index_unique(us, w, skew_param, seed=0, device=0, on_device=True, max_rounds=4, log=None, check=True, **build_opts):
     """build the SSHash of a synthetic unitig set and make its canonical k-mers unique: duplicates reported by the device
     validate_self (a few at GRCh38 scale: the birthday bound of random sequence) are broken up by substituting one base
     in the middle of the later copy, and the index is rebuilt.  Returns (index, report, rounds).  check=False builds once and
-    validates nothing (stage-cost experiments with kernels whose results are meaningless)."""
+    validates nothing (stage-cost experiments with kernels whose results are meaningless).  build_opts: the layout choices of
+    SSHash.from_unitig_set_opts (minimizer_lines, lines_max_load, direct_bytes_per_key)."""
     from . import kphf
     import numpy as np
     k = us["k"]
@@ -133,8 +134,7 @@ def build_index_unique(us, w, skew_param, seed=0, device=0, on_device=True, max_
         words_h = us["words"].cpu().numpy().view(np.uint64)
         starts_h = us["starts"].cpu().numpy().view(np.uint64)
         uset = kphf.UnitigSet.from_packed(words_h, us["total_len"], starts_h, k)
-        ix = (kphf.SSHash.from_unitig_set_on_device(uset, w, skew_param, seed, device=device) if on_device
-              else kphf.SSHash.from_unitig_set(uset, w, skew_param, seed))
+        ix = kphf.SSHash.from_unitig_set_opts(uset, w, skew_param, seed, device=device if on_device else -1, **build_opts)
         del uset
         ix.to_device(device)
         if not check:

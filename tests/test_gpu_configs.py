@@ -45,19 +45,18 @@ def _k2u_device(ix, q):
     return out, cnt.cpu().tolist()
 
 
-@pytest.mark.parametrize("front", ["1", "0"])
-def test_s_eighth_headline_kernel_matches_oracle(monkeypatch, front):
+@pytest.mark.parametrize("front", [1, -1])
+def test_s_eighth_headline_kernel_matches_oracle(front):
     """BASELINE configs[3] at 1/8 scale (452 Mbp, 4.5 M unitigs): same kernel specialisation and index form as the headline.
     front=1: minimizer lines (the form the full-size sets get by the size rule, forced here); front=0: the minimizer
     record -> entry array path with the records' negative filter (what spilled buckets and small sets use)"""
     import torch
     from mazu_amd import synth
-    monkeypatch.setenv("MZ_FRONT_TABLE", front)
     us = synth.make_unitig_set("s-eighth", device="cuda")
     assert us["total_len"] == 3_589_802_592 // 8
-    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log, minimizer_lines=front)  # mz_build_opts: lines forced / never built
     assert ix.minimizer_mphf_kind() == 1 and ix.n_kmers_in_skew_index() > 0  # direct minimizer records + a populated skew table
-    assert ix.has_minimizer_lines() == (front == "1")
+    assert ix.has_minimizer_lines() == (front == 1)
     assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and rep["n_kmers"] == ix.n_kmers()
     q = synth.make_query_mix(ix, us, 2_000_000, seed=11, device="cuda")                         # 50/50 NEG-U
     q1 = synth.make_query_mix(ix, us, 400_000, seed=12, device="cuda", neg_kind="sub1")        # 200 k positives + 200 k NEG-1
@@ -72,22 +71,22 @@ def test_s_eighth_headline_kernel_matches_oracle(monkeypatch, front):
     assert abs(n_hit - 1_200_000) <= 8  # positives hit; NEG-U / NEG-1 negatives miss (up to accidental members)
 
 
-@pytest.mark.parametrize("bytes_per_key,kind,reads_lines,resolve", [("48", 1, None, None), ("48", 1, "1", "run"), ("48", 1, "1", "item"), ("16", 0, None, None)])
-def test_s_txome_reads_match_oracle_streaming_walk(monkeypatch, bytes_per_key, kind, reads_lines, resolve):
+@pytest.mark.parametrize("bytes_per_key,kind,reads_lines,resolve,verify", [(48, 1, None, None, None), (48, 1, "lines", "run", None), (48, 1, "lines", "item", None),
+                                                                            (16, 0, None, None, None), (48, 1, None, None, "group"), (48, 1, "lines", "item", "group")])
+def test_s_txome_reads_match_oracle_streaming_walk(bytes_per_key, kind, reads_lines, resolve, verify):
     """BASELINE configs[2] shape: 150-bp reads over a 145 Mbp, 1.2 M-unitig set, requested as .as_streaming();
     every window must equal the oracle's StreamingK2U walk (index/caching.rs:65-103, bin/kphf/main.rs:299-312).
     Once with the direct-address minimizer records the size rule picks for this set (the reads kernel then resolves one
     minimizer per run of windows through the records, although the index also has minimizer lines), once through the
-    minimizer lines (what the kernel does on large indexes), once with the BBHash levels the rule picks for smaller sets."""
+    minimizer lines (what the kernel does on large indexes), once with the BBHash levels the rule picks for smaller sets; and
+    with the grouped verify-and-extend finish instead of one sequence-record gather per candidate.  All choices go through
+    mz_build_opts / mz_query_opts."""
     import torch
     from mazu_amd import synth
-    monkeypatch.setenv("MZ_DIRECT_BYTES_PER_KEY", bytes_per_key)
-    if reads_lines is not None:
-        monkeypatch.setenv("MZ_READS_LINES", reads_lines)
-    if resolve is not None:  # through the lines: one lookup per run of windows, or every window scanning its line (the default on large indexes)
-        monkeypatch.setenv("MZ_READS_RESOLVE", resolve)
     us = synth.make_unitig_set("s-txome", device="cuda")
-    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log, direct_bytes_per_key=bytes_per_key)
+    # through the lines: one lookup per run of windows, or every window scanning its line (the rule on large indexes)
+    ix.set_query_opts(reads_lines=reads_lines, reads_resolve=resolve, reads_verify=verify)
     assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and ix.minimizer_mphf_kind() == kind
     assert ix.has_minimizer_lines() == (kind == 1)
     n_reads, read_len = 20_000, 150
@@ -105,6 +104,84 @@ def test_s_txome_reads_match_oracle_streaming_walk(monkeypatch, bytes_per_key, k
     got = out.cpu().numpy().view(M.K2UPOS_DTYPE)
     assert got.tobytes() == want.tobytes() and cnt.cpu().tolist() == oc.tolist()
     assert 0.3 < oc[0] / (n_reads * 120) < 0.99  # junction windows and substituted reads miss, the rest hit
+
+
+def _crafted_reads(us, rng):
+    """reads that exercise the verify-and-extend finish of the reads kernel: whole reads on the reverse strand, reads that hop from one
+    unitig to a distant one (in both strands), non-ACGT bytes, and lengths that put read ends on every side of the 256-position
+    tile edges; returns (bases uint8, read_offsets uint64)"""
+    words = us["words"].cpu().numpy().view(np.uint64)
+    starts = us["starts"].cpu().numpy().astype(np.int64)
+    L = us["total_len"]
+
+    def seq(a, n):  # codes of bases [a, a + n) of the unitig concatenation
+        i = np.arange(a, a + n, dtype=np.int64)
+        return ((words[i >> 5] >> ((i & 31) * 2).astype(np.uint64)) & np.uint64(3)).astype(np.uint8)
+
+    def rc(c):
+        return (3 - c)[::-1]
+
+    long_u = np.nonzero(starts[1:] - starts[:-1] >= 200)[0]
+    reads = []
+    for j in range(300):  # single-unitig reads, forward and reverse, lengths around the tile edges
+        u = int(long_u[rng.integers(len(long_u))])
+        n = int(rng.choice([31, 32, 63, 64, 65, 127, 128, 129, 150, 199, 200]))
+        a = int(starts[u] + rng.integers(0, starts[u + 1] - starts[u] - n + 1))
+        c = seq(a, n)
+        reads.append(rc(c) if j % 2 else c)
+    for j in range(300):  # hops: the tail of one unitig, then the head of another one far away; half of them reverse-complemented
+        u, v = (int(long_u[rng.integers(len(long_u))]) for _ in range(2))
+        na, nb = int(rng.integers(31, 100)), int(rng.integers(31, 100))
+        c = np.concatenate([seq(int(starts[u + 1]) - na, na), seq(int(starts[v]), nb)])
+        reads.append(rc(c) if j % 2 else c)
+    for j in range(100):  # reads across the junctions of the concatenation itself (the windows on a junction miss)
+        u = int(rng.integers(1, len(starts) - 2))
+        a = max(0, int(starts[u]) - int(rng.integers(20, 120)))
+        reads.append(seq(a, min(150, L - a)))
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = [letters[c] for c in reads]
+    for j in range(0, len(out), 7):  # non-ACGT bytes: windows over them are skipped, the stretches on either side continue
+        r = out[j].copy()
+        r[int(rng.integers(len(r)))] = ord("N")
+        if len(r) > 100:
+            r[int(rng.integers(len(r)))] = ord("n")
+        out[j] = r
+    out += [np.frombuffer(b"ACGTACGTAC", dtype=np.uint8), np.zeros(0, dtype=np.uint8), letters[seq(int(starts[5]), 30)]]  # too short for a window, empty
+    # lengths 256 / 512 so that reads end exactly on tile edges wherever they start
+    out += [letters[seq(int(rng.integers(0, L - 600)), n)] for n in (256, 512, 256, 255, 257, 1, 256)]
+    order = rng.permutation(len(out))
+    out = [out[i] for i in order]
+    ro = np.zeros(len(out) + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in out], out=ro[1:].view(np.int64))
+    return np.concatenate(out), ro
+
+
+@pytest.mark.parametrize("reads_lines", ["records", "lines"])
+def test_s_txome_crafted_reads_every_finish(reads_lines):
+    """index/caching.rs:65-103 walks forward along one unitig; the device finish verifies stretches in either direction and across
+    unitig hops.  Crafted reads -- reverse strand, unitig-to-unitig hops, N breaks, ends on tile edges, empty and short reads --
+    through every combination of resolve and verify forms must equal the oracle's streaming walk record for record."""
+    import torch
+    from mazu_amd import synth
+    us = synth.make_unitig_set("s-txome", device="cuda")
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
+    assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0
+    words, starts = _host_arrays(us)
+    orc = O.OracleSSHash(words, us["total_len"], starts, 31, 15, 32, with_dict=False)
+    for seed in (1, 2):
+        bases, ro = _crafted_reads(us, np.random.default_rng(seed))
+        want, ko_h, oc = orc.k2u_reads(bases, ro, streaming=True)
+        assert oc[2] > 0 and 0.3 < oc[0] / max(1, len(want)) < 0.99  # skipped windows exist; hits and misses both
+        d_b, d_ro, d_ko = (torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x).cuda() for x in (bases, ro, ko_h))
+        for resolve in ("item", "run"):
+            for verify in ("each", "group"):
+                ix.set_query_opts(reads_lines=reads_lines, reads_resolve=resolve, reads_verify=verify)
+                out = torch.zeros(len(want) * 2, dtype=torch.int64, device="cuda")
+                cnt = torch.zeros(3, dtype=torch.int64, device="cuda")
+                ix.k2u_reads_device(d_b, d_ro, d_ko, out, cnt, streaming=True, stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                got = out.cpu().numpy().view(M.K2UPOS_DTYPE)
+                assert got.tobytes() == want.tobytes() and cnt.cpu().tolist() == oc.tolist(), (seed, resolve, verify)
 
 
 def _full_size_properties(preset, n_q):
@@ -159,23 +236,57 @@ def _full_size_properties(preset, n_q):
     for i in range(31):
         fw |= code[:, i:i + read_len - 30] << (2 * i)
     want, (wh, wm, _) = _k2u_device(ix, fw.reshape(-1).contiguous())
-    for resolve in ("item", "run"):
-        os.environ["MZ_READS_RESOLVE"] = resolve
-        try:
-            got = torch.empty(2 * n_win, dtype=torch.int64, device=dev)
-            cnt = torch.zeros(3, dtype=torch.int64, device=dev)
-            ix.k2u_reads_device(bases, ro, ko, got, cnt, streaming=True)
-            torch.cuda.synchronize()
-        finally:
-            os.environ.pop("MZ_READS_RESOLVE", None)
-        assert torch.equal(got, want), resolve
+    for resolve, verify in (("item", "each"), ("run", "each"), ("item", "group"), ("run", "group")):
+        ix.set_query_opts(reads_resolve=resolve, reads_verify=verify)
+        got = torch.empty(2 * n_win, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(3, dtype=torch.int64, device=dev)
+        ix.k2u_reads_device(bases, ro, ko, got, cnt, streaming=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (resolve, verify)
         assert cnt.cpu().tolist() == [wh, wm, 0] and 0.3 < wh / n_win < 0.99
+    ix.set_query_opts()
     return ix
 
 
 def test_s_human_full_size_properties():
     """BASELINE configs[3] on one GPU's replica: 36 145 130 unitigs, 3 589 802 592 bp (reference src/cuttlefish.rs:25-44)"""
     _full_size_properties("s-human", 4_000_000)
+
+
+def test_s_human_reads_match_oracle_streaming_walk():
+    """100 000 reads (12 M windows) on the full-size GRCh38-shaped set against the ORACLE's StreamingK2U walk (its own index,
+    built here from the same unitig set), through both verify forms: no self-comparison at the headline size"""
+    import torch
+    from mazu_amd import synth
+    us = synth.make_unitig_set("s-human", device="cuda")
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
+    assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0
+    n_reads, read_len = 100_000, 150
+    bases, ro = synth.make_reads(us, n_reads, read_len, seed=2000, device="cuda")
+    ko = synth.kmer_offsets(ro, 31)
+    n_win = int(ko[-1])
+    got = {}
+    for verify in ("each", "group"):
+        ix.set_query_opts(reads_verify=verify)
+        out = torch.zeros(n_win * 2, dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(3, dtype=torch.int64, device="cuda")
+        ix.k2u_reads_device(bases, ro, ko, out, cnt, streaming=True, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got[verify] = (out.cpu().numpy().view(M.K2UPOS_DTYPE), cnt.cpu().tolist())
+    bases_h, ro_h = bases.cpu().numpy(), ro.cpu().numpy().astype(np.uint64)
+    del ix, out, bases, ro, ko
+    torch.cuda.empty_cache()
+    words, starts = _host_arrays(us)
+    total = us["total_len"]
+    del us
+    os.environ["OMP_NUM_THREADS"] = str(M.lib.mz_host_threads())
+    _log("building the oracle's index of s-human on the host ...")
+    orc = O.OracleSSHash(words, total, starts, 31, 15, 32, with_dict=False)
+    _log("oracle streaming walk over 12 M windows ...")
+    want, _, oc = orc.k2u_reads(bases_h, ro_h, streaming=True)
+    for verify, (g, c) in got.items():
+        assert g.tobytes() == want.tobytes() and c == oc.tolist(), verify
+    assert 0.3 < oc[0] / n_win < 0.99
 
 
 def test_s_pan_full_size_properties():

@@ -56,10 +56,10 @@ def test_random_configurations_match_the_dictionary(block):
                 assert np.array_equal(got["match"] != 0, truth["match"] != 0), what
 
 
-def test_folded_lines_retry_when_a_line_overflows(monkeypatch, tmp_path):
+def test_folded_lines_retry_when_a_line_overflows(tmp_path):
     """A minimizer-line table folded so hard that some line would hold more than 16 member keys is rebuilt with less folding,
     identically by the host and the GPU builder (the flat files are compared byte for byte), and answers like the dictionary."""
-    monkeypatch.setenv("MZ_FRONT_MAX_LOAD", "1000")  # start from the fewest lines the slot's key field allows
+    # mz_build_opts.lines_max_load = 1000: start from the fewest lines the slot's key field allows
     rng = np.random.default_rng(77)
     for c, (k, w) in enumerate([(31, 11), (25, 9), (31, 12)]):
         seed = int(rng.integers(0, 1 << 30))
@@ -72,7 +72,7 @@ def test_folded_lines_retry_when_a_line_overflows(monkeypatch, tmp_path):
         truth, _ = orc.k2u_batch(q, n_threads=8, use_dict=True)
         files = []
         for how in ("host", "gpu"):
-            ix = M.SSHash.from_unitig_set(us, w, 32, seed) if how == "host" else M.SSHash.from_unitig_set_on_device(us, w, 32, seed)
+            ix = M.SSHash.from_unitig_set_opts(us, w, 32, seed, device=-1 if how == "host" else 0, lines_max_load=1000)
             assert ix.has_minimizer_lines(), (c, how)
             got, _ = ix.k2u_batch(q)
             rep = ix.validate_self_report()
@@ -89,12 +89,11 @@ def test_folded_lines_retry_when_a_line_overflows(monkeypatch, tmp_path):
             assert f.has_front and f.front_g + f.front_t < 8 and f.n("front_lines") == 16 * 4 ** w >> (f.front_g + f.front_t)
 
 
-@pytest.mark.parametrize("reads_lines", ["1", "0"])
-def test_bucket_larger_than_a_marker_can_say_without_a_skew_index(monkeypatch, reads_lines):
+@pytest.mark.parametrize("reads_lines", ["lines", "records"])
+def test_bucket_larger_than_a_marker_can_say_without_a_skew_index(reads_lines):
     """90 000 unitigs that all carry one 21-base motif between unique flanks: without a skew index their shared minimizer owns a
     bucket whose size does not fit the 16-bit count of a minimizer-line spill marker, so lookups through the lines (point queries,
     and reads resolved per run of windows) must fall back to the exact in-order walk of sshash.rs:494-553."""
-    monkeypatch.setenv("MZ_READS_LINES", reads_lines)
     rng = np.random.default_rng(5)
     k, w, n = 31, 11, 90000
     motif = rng.integers(0, 4, 21, dtype=np.uint8)
@@ -110,6 +109,7 @@ def test_bucket_larger_than_a_marker_can_say_without_a_skew_index(monkeypatch, r
     orc = O.OracleSSHash(words, total, starts, k, w, M.MZ_NO_SKEW_INDEX, 0)
     us = M.UnitigSet.from_packed(words, total, starts, k)
     ix = M.SSHash.from_unitig_set_no_skew_index(us, w)
+    ix.set_query_opts(reads_lines=reads_lines)
     assert ix.has_minimizer_lines() and ix.minimizer_mphf_kind() == 1
     q = H.query_mix(words, starts, k, 60000, seed=3)
     truth, _ = orc.k2u_batch(q, n_threads=8, use_dict=True)
