@@ -256,7 +256,8 @@ uint64_t mz_u2pos_n_unitig_occs(const mz_u2pos *u, uint64_t ui); /* n_unitig_occ
 uint64_t mz_u2pos_num_total_occs(const mz_u2pos *u);             /* :34-36 */
 /* project_onto_u_occs (index.rs:184-216) for a batch of K2UPos records in HBM: d_offsets (n+1) receives the exclusive
  * prefix sums of the per-query occurrence counts (d_offsets[n] = total), d_out (may be NULL to only count) the
- * MappedRefPos records of query i at [d_offsets[i], d_offsets[i+1]); records beyond out_cap are not written. */
+ * MappedRefPos records of query i at [d_offsets[i], d_offsets[i+1]); records beyond out_cap are not written.
+ * n <= 2^32 - 1 (a record's `query` field holds 32 bits; MZ_EINVAL beyond; the same limit holds for mz_get_ref_pos_batch). */
 int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets,
                             mz_mapped_ref_pos *d_out, uint64_t out_cap, void *stream);
 /* place the table in the HBM of `device` now (otherwise done on first use) and prepare that GPU for the entry point below */
@@ -266,8 +267,9 @@ int mz_u2pos_to_device(mz_u2pos *u, int device);
  * in a fixed array inside the library (128 KiB per GPU, held until the process ends) instead of stream-ordered scratch, and
  * it calls no allocating routine.  Limits: n <= mz_u2pos_noalloc_max_queries() (2^24; MZ_EINVAL beyond), the table must
  * already be resident on the GPU that owns d_offsets (mz_u2pos_to_device; MZ_EINVAL otherwise).  Every call on one GPU uses
- * that GPU's one array: calls that overlap in time on the same GPU (different streams or threads) race and must be
- * serialised by the caller. */
+ * that GPU's one array.  Calls from different streams or host threads are ordered on the device by the library (each call's
+ * stream waits for the previous call's last kernel); calls recorded under stream capture are not -- graphs that contain
+ * this entry point and may run at the same time on one GPU race and must be serialised by their owner. */
 int mz_u2pos_project_device_noalloc(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets,
                                     mz_mapped_ref_pos *d_out, uint64_t out_cap, void *stream);
 uint64_t mz_u2pos_noalloc_max_queries(void);

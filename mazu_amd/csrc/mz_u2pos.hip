@@ -5,6 +5,8 @@
 // count -> exclusive scan -> fill, all on the device.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -244,20 +246,38 @@ constexpr uint64_t kNoAllocMaxQueries = 1ull << 24;                       // 16 
 constexpr uint64_t kNoAllocMaxTiles = kNoAllocMaxQueries / kTileN;       // 16384 tiles
 static __device__ __align__(256) uint64_t scratch[kNoAllocMaxTiles + 2];
 constexpr int kMaxDevices = 64;
-uint64_t *g_scratch_ptr[kMaxDevices] = {}; // device address of `scratch` on each GPU, resolved by mz_u2pos_to_device
+std::atomic<uint64_t *> g_scratch_ptr[kMaxDevices]; // device address of `scratch` on each GPU, resolved by mz_u2pos_to_device (zero-initialised: static storage)
 std::mutex g_scratch_mu;
 
-// device address of this GPU's copy of `scratch`; `device` must be the current device
+// device address of GPU `device`'s copy of `scratch`.  Every GPU holds its own copy at its own address and
+// hipGetSymbolAddress answers for the CURRENT device, so the device is made current here, whatever the caller left current, and
+// the address is checked to belong to it before it is kept.
 int resolve_scratch(int device) {
     if (device < 0 || device >= kMaxDevices) { set_error("device %d beyond the %d devices the no-allocation path tracks", device, kMaxDevices); return MZ_EINVAL; }
     std::lock_guard<std::mutex> g(g_scratch_mu);
-    if (g_scratch_ptr[device]) return MZ_OK;
+    if (g_scratch_ptr[device].load(std::memory_order_acquire)) return MZ_OK;
+    DeviceGuard guard;
+    U2_HIP(hipSetDevice(device));
     uint64_t *p = nullptr;
     U2_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
     if (!p) { set_error("hipGetSymbolAddress returned a null address for the scratch array"); return MZ_EHIP; }
-    g_scratch_ptr[device] = p;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) {
+        if (attr.device != device) { set_error("scratch array resolved on device %d, wanted %d", attr.device, device); return MZ_EHIP; }
+    } else {
+        (void)hipGetLastError(); // (a runtime that does not classify symbol addresses: the device was made current above)
+    }
+    g_scratch_ptr[device].store(p, std::memory_order_release);
     return MZ_OK;
 }
+// Calls of the no-allocation entry point share their GPU's one array: a call whose kernels start while those of the previous one are
+// still running on ANOTHER stream would corrupt that call's scan.  An event is recorded behind each call's last kernel, and a call
+// on a different stream makes its stream wait for it first: calls on one GPU are then ordered on the device whatever streams and
+// host threads they come from (no allocation: the event is created by mz_u2pos_to_device).  Not under stream capture, where events
+// from outside the graph cannot be waited for: a captured graph is serialised by its owner.
+struct NoAllocInFlight { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool armed = false; };
+NoAllocInFlight g_noalloc_busy[kMaxDevices];
+std::mutex g_noalloc_mu[kMaxDevices];
 
 __global__ void zero_word_kernel(uint64_t *p) { *p = 0; }
 
@@ -363,6 +383,7 @@ uint64_t mz_u2pos_num_total_occs(const mz_u2pos *u) { return u->n_occs; }
 int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, uint64_t n, uint64_t *d_offsets, mz_mapped_ref_pos *d_out,
                             uint64_t out_cap, void *stream_) {
     if (!u || !d_offsets || (n && !d_recs)) { set_error("null argument"); return MZ_EINVAL; }
+    if (n > 0xFFFFFFFFull) { set_error("mz_u2pos_project_device: %llu queries; a record's `query` field holds 32 bits: split the batch", (unsigned long long)n); return MZ_EINVAL; }
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard;
     int rc = ensure_u2pos_device(u, device_of(d_offsets));
@@ -384,9 +405,16 @@ int mz_u2pos_project_device(mz_u2pos *u, uint32_t k, const mz_k2upos *d_recs, ui
 int mz_u2pos_to_device(mz_u2pos *u, int device) {
     if (!u) { set_error("null argument"); return MZ_EINVAL; }
     DeviceGuard guard;
-    int rc = ensure_u2pos_device(u, device); // makes `device` current
+    int rc = ensure_u2pos_device(u, device); // (returns early, without touching the current device, when the table is resident already)
     if (rc != MZ_OK) return rc;
-    return resolve_scratch(device);
+    rc = resolve_scratch(device);
+    if (rc != MZ_OK) return rc;
+    std::lock_guard<std::mutex> busy_lock(g_noalloc_mu[device]);
+    if (!g_noalloc_busy[device].ev) { // the in-flight guard's event of this GPU, created here so that the entry point itself creates nothing
+        U2_HIP(hipSetDevice(device));
+        U2_HIP(hipEventCreateWithFlags(&g_noalloc_busy[device].ev, hipEventDisableTiming));
+    }
+    return MZ_OK;
 }
 
 uint64_t mz_u2pos_noalloc_max_queries(void) { return kNoAllocMaxQueries; }
@@ -401,16 +429,25 @@ int mz_u2pos_project_device_noalloc(mz_u2pos *u, uint32_t k, const mz_k2upos *d_
     }
     hipStream_t stream = (hipStream_t)stream_;
     const int device = device_of(d_offsets);
-    uint64_t *d_tiles = device >= 0 && device < kMaxDevices ? g_scratch_ptr[device] : nullptr;
+    uint64_t *d_tiles = device >= 0 && device < kMaxDevices ? g_scratch_ptr[device].load(std::memory_order_acquire) : nullptr;
     if (!u->d_ctable || u->device != device || !d_tiles) {
         set_error("mz_u2pos_project_device_noalloc: the table is not resident on device %d; call mz_u2pos_to_device(u, %d) once beforehand", device, device);
         return MZ_EINVAL;
     }
     DeviceGuard guard;
     U2_HIP(hipSetDevice(device));
+    // the in-flight guard: none under stream capture (events cannot be queried there; a captured graph is serialised by its owner)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    std::lock_guard<std::mutex> busy_lock(g_noalloc_mu[device]);
+    NoAllocInFlight &fl = g_noalloc_busy[device];
+    if (cap == hipStreamCaptureStatusNone && fl.armed && fl.stream != stream) U2_HIP(hipStreamWaitEvent(stream, fl.ev, 0));
     if (n == 0) hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(1), 0, stream, d_offsets); // a kernel, not a memset node: safe under graph capture
     else launch_project(u, k, d_recs, n, d_offsets, d_out, out_cap, d_tiles, stream);
     U2_HIP(hipGetLastError());
+    if (cap == hipStreamCaptureStatusNone && fl.ev) { // (the event is created by mz_u2pos_to_device: nothing is allocated here)
+        if (hipEventRecord(fl.ev, stream) == hipSuccess) { fl.stream = stream; fl.armed = true; } else { (void)hipGetLastError(); fl.armed = false; }
+    }
     return MZ_OK;
 }
 
@@ -495,6 +532,7 @@ int mz_get_ref_pos_batch(mz_sshash *ix, mz_u2pos *u, const uint64_t *fw_words, u
     *n_out = 0;
     hit_offsets[0] = 0;
     if (n == 0) return MZ_OK;
+    if (n > 0xFFFFFFFFull) { set_error("mz_get_ref_pos_batch: %llu queries; a record's `query` field holds 32 bits: split the batch", (unsigned long long)n); return MZ_EINVAL; }
     if (!out) out_cap = 0;
     DeviceGuard guard;
     int device = 0; // the replica the handle's host-pointer entry points use; the handle is not retargeted

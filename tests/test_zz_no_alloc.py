@@ -70,3 +70,34 @@ def test_noalloc_projection_equals_the_allocating_entry_point():
     with pytest.raises(MazuError) as e:
         check(lib.mz_u2pos_project_device_noalloc(u, k, d_recs.data_ptr(), cap + 1, d_off.data_ptr(), None, 0, None))
     assert e.value.code == MZ_EINVAL and "exceed" in str(e.value)
+
+
+def test_noalloc_after_the_table_became_resident_through_another_entry_point_and_across_streams():
+    """the set-up call must resolve the scratch array of ITS device also when the table is resident already (it then returns early from the
+    upload and must not rely on whatever device is current), and calls issued on two different streams back to back are ordered on
+    the device by the library: both see correct results"""
+    import torch
+    idx, f = I.dense_index_from_pf1(os.path.join(PF1, "yeast_chr01_index"), lambda words, total, starts, k:
+                                    M.SSHash.from_unitig_set(M.UnitigSet.from_packed(words, total, starts, k), 15, 32))
+    k = f.k
+    table = I.DenseUnitigTable(idx.u2pos.ctable, idx.u2pos.contig_offsets, idx.u2pos.ref_names)
+    u = table.handle()
+    fw = idx.refs.kmer_words(0, k)
+    dq = torch.from_numpy(fw.view(np.int64)).cuda()
+    n = len(fw)
+    d_recs = torch.empty(2 * n, dtype=torch.int64, device="cuda")
+    idx.k2u.k2u_batch_device(dq, d_recs, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want_off, want = _project(lib.mz_u2pos_project_device, u, k, d_recs, n, torch)  # makes the table resident
+    check(lib.mz_u2pos_to_device(u, torch.cuda.current_device()))                    # early-return path of the upload
+    total = len(want)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    offs = [torch.full((n + 1,), -1, dtype=torch.int64, device="cuda") for _ in range(2)]
+    outs = [torch.full((max(total, 1) * 2,), -1, dtype=torch.int64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for j, st in enumerate((s1, s2)):  # no synchronisation between the two calls
+        check(lib.mz_u2pos_project_device_noalloc(u, k, d_recs.data_ptr(), n, offs[j].data_ptr(), outs[j].data_ptr(), total, st.cuda_stream))
+    torch.cuda.synchronize()
+    for j in range(2):
+        assert offs[j].cpu().numpy().tobytes() == want_off.tobytes(), j
+        assert outs[j][: 2 * total].cpu().numpy().view(MAPPED).tobytes() == want.tobytes(), j
