@@ -109,6 +109,11 @@ def self_launch(args, argv):
     return rc
 
 
+def query_seed(rank):
+    """seed of a rank's query shard (point queries; reads use 2000 + rank): different on every rank, the same from run to run"""
+    return 1000 + rank
+
+
 def launch_check(args):
     """the N>1 plumbing without an index: process group, the path's one collective, max-over-ranks timing"""
     import torch
@@ -123,15 +128,74 @@ def launch_check(args):
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(dev)
     D.init(backend, dev)
+    warm_collectives(D, dev or "cpu", torch) if dev is not None else (D.allreduce_counts(torch.zeros(3, dtype=torch.int64)), D.barrier())
     counts = torch.tensor([rank + 1, 10 * (rank + 1), 0], dtype=torch.int64, device=dev or "cpu")
     D.allreduce_counts(counts)
     t = D.max_over_ranks(float(rank + 1), dev or "cpu")
+    # every rank draws its shard from its own seed (1000 + rank in the real run): the seeds of all ranks, gathered through the same collective
+    seeds = torch.zeros(world, dtype=torch.int64, device=dev or "cpu")
+    seeds[rank] = query_seed(rank)
+    D.allreduce_counts(seeds)
+    # the accounting of the real run on a pretend batch: value x ms_per_step == world x batch
+    batch, steps, elapsed = 1000, 4, 0.25 * t
+    value, ms_per_step = batch * world * steps / elapsed / 1e6, elapsed / steps * 1e3
     D.barrier()
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": backend, "counts": counts.cpu().tolist(), "max_over_ranks": t}), flush=True)
+        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": backend, "counts": counts.cpu().tolist(), "max_over_ranks": t,
+                          "query_seeds": seeds.cpu().tolist(), "value": value, "ms_per_step": ms_per_step, "batch": batch,
+                          "collective": collective_info(backend, world)}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def collective_info(backend, world):
+    """what carried the path's one exchange step: read from the process group itself, so that the line says whether RCCL saw N ranks"""
+    import torch
+    import torch.distributed as dist
+    info = {"backend": backend if world > 1 else "none (single process)", "world_size": world, "rccl_version": None}
+    if world > 1 and dist.is_initialized():
+        info["backend"] = dist.get_backend()
+        info["world_size"] = dist.get_world_size()
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:  # torch built without the binding
+        pass
+    return info
+
+
+def warm_collectives(D, dev, torch):
+    """the path's collectives once, untimed, on scratch tensors: the first all_reduce of a communicator sets up its rings and
+    buffers (milliseconds), which must not land inside a timed region of a tenth of a second"""
+    scratch = torch.zeros(3, dtype=torch.int64, device=dev)
+    D.allreduce_counts(scratch)
+    D.max_over_ranks(0.0, dev)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+
+
+def kernel_source_hash():
+    """hash of the sources every kernel of the hot path is compiled from: a traffic figure measured under the profiler is only
+    printed for the kernels it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mz_device.hip", "mz_common.hpp"):
+        with open(os.path.join(ROOT, "mazu_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_record(key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of the same command (profiles/traffic_per_launch.json), or None
+    when there is none for this workload, or when the kernels have changed since it was taken"""
+    tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
+    if not os.path.exists(tf):
+        return None
+    rec = json.load(open(tf)).get(key)
+    if not rec or rec.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    return rec
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -241,6 +305,7 @@ def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
     for _ in range(args.warmup):
         step()
     counts.zero_()
+    warm_collectives(D, dev, torch)
     torch.cuda.synchronize(dev)
     D.barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -263,7 +328,8 @@ def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
                "config": {"workload": f"{args.workload}: {args.n_reads} x {args.read_len} bp reads per GPU per step (50% with 1% substitutions, "
                                       f"random strand, drawn across unitig junctions), SSHash k=31 m={args.w} skew_param={args.skew}",
                           "windows_per_gpu_per_step": n_win, "n_kmers": ix.n_kmers()},
-               "hit_fraction": round(n_hit / max(1, n_hit + n_miss), 4), "skipped": n_skip}
+               "hit_fraction": round(n_hit / max(1, n_hit + n_miss), 4), "skipped": n_skip, "timed_region_s": round(elapsed, 4),
+               "collective": collective_info(os.environ.get("MZ_DIST_BACKEND", "nccl"), world)}
         if world == 1 and not args.no_cpu_baseline:  # parity of a sample of reads against the oracle
             os.environ["OMP_NUM_THREADS"] = str(M.lib.mz_host_threads())
             from oracle import oracle as O
@@ -283,12 +349,19 @@ def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
             f_cold = orc.last_reads_cold / max(1, len(want) - int((want["match"] == 3).sum()))
             b_win = B_ALG * f_cold + 17.0 * (1.0 - f_cold)
             achieved = n_win * b_win / kernel_s / 1e9
-            tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")  # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload only)
-            rec = json.load(open(tf)).get(f"reads:{args.workload}:{n_win}") if os.path.exists(tf) and args.err_frac == 0.5 else None
+            # HBM bytes and VALU wave-instructions per launch from the committed rocprofv3 --pmc passes (same workload and kernels only).  `frac`
+            # prices the windows at what the REFERENCE's walk would move; `traffic_gbs` is what this kernel moves, and `issue` says what bounds
+            # it: VALU wave-instructions per 64 windows, and the fraction of the SIMDs' issue slots they fill (4 cycles each at 2.4 GHz)
+            rec = traffic_record(f"reads:{args.workload}:{n_win}") if args.err_frac == 0.5 and not any(ix.get_query_opts().values()) else None
             res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec["hbm_bytes_per_launch"] if rec else None,
+                               "traffic_gbs": round(rec["hbm_bytes_per_launch"] / kernel_s / 1e9, 1) if rec else None,
                                "kernel": "k2u_reads_wave_kernel" if args.w == 15 else "k2u_reads_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4),
                                "algorithmic_bytes_per_window": round(b_win, 1), "f_cold": round(f_cold, 4)}
+            if rec and rec.get("valu_wave_insts_per_launch"):
+                n_simd, clk = 1024, 2.4e9
+                res["roofline"]["issue"] = {"valu_per_64_windows": round(rec["valu_wave_insts_per_launch"] / n_win * 64, 1),
+                                            "valu_issue_frac": round(rec["valu_wave_insts_per_launch"] * 4 / (n_simd * clk * kernel_s), 3)}
             assert same, "GPU read results differ from the oracle's streaming walk"
         print(json.dumps(res), flush=True)
     if world > 1:
@@ -361,7 +434,7 @@ def main():
     if args.mode == "reads":
         return bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch)
     # ---- this rank's shard of the query batch, generated in HBM
-    q = synth.make_query_mix(ix, us, batch, seed=1000 + rank, device=dev, neg_frac=args.neg_frac, neg_kind=args.neg_kind)
+    q = synth.make_query_mix(ix, us, batch, seed=query_seed(rank), device=dev, neg_frac=args.neg_frac, neg_kind=args.neg_kind)
     out = torch.empty(batch * 2, dtype=torch.int64, device=dev)
     counts = torch.zeros(3, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -377,6 +450,7 @@ def main():
     for _ in range(args.warmup):
         step()
     counts.zero_()
+    warm_collectives(D, dev, torch)  # the communicator's first all_reduce happens here, not inside the timed region
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
@@ -397,9 +471,8 @@ def main():
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
         achieved = batch * B_ALG / avg_kernel_s / 1e9
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.exists(tf) and args.neg_frac == 0.5 and args.neg_kind == "uniform":  # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload/batch only)
-            rec = json.load(open(tf)).get(f"{args.workload}:{batch}")
+        if args.neg_frac == 0.5 and args.neg_kind == "uniform" and args.w == 15 and not ix.get_query_opts()["point_kernel"]:  # (same workload, batch and kernel only)
+            rec = traffic_record(f"{args.workload}:{batch}")
             traffic = rec["hbm_bytes_per_launch"] if rec else None
         res = {
             "metric": "M k-mers/sec looked up (whole node), GRCh38 k=31, at 1/2/4/8 MI355X",
@@ -418,6 +491,7 @@ def main():
                          "traffic_gbs": round(traffic / avg_kernel_s / 1e9, 1) if traffic else None,
                          "kernel": {3: "k2u_batch_kernel", 2: "k2u_tile_kernel"}.get(ix.get_query_opts()["point_kernel"], "k2u_wave_kernel"), "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_kmer": B_ALG},
+            "timed_region_s": round(elapsed, 4), "collective": collective_info(backend, n_gpus),
             "build": {"gen_s": round(t_gen, 2), "where": "host" if args.host_build else "gpu", "build_and_validate_s": round(t_build, 2),
                       "rebuilds_for_duplicates": rebuilds, "bits_per_kmer": round(ix.num_bits() / ix.n_kmers(), 2)},
         }

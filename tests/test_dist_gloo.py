@@ -86,6 +86,23 @@ def test_bench_gpus_n_launches_n_ranks_itself():
     assert res["n_gpus"] == 2 and res["counts"] == [3, 30, 0] and res["max_over_ranks"] == 2.0
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_launch_check_at_world_4_and_8(world):
+    """the launch of the 4- and 8-GPU runs rehearsed on the CPU (gloo): every rank joins, the warm-up collectives and the path's
+    all-reduce run, every rank draws from its own seed, and the line's accounting holds: value x ms_per_step == world x batch"""
+    import json
+    r = _run_bench({"MZ_DIST_BACKEND": "gloo"}, "--gpus", str(world), "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    tri = world * (world + 1) // 2
+    assert res["n_gpus"] == world and res["counts"] == [tri, 10 * tri, 0] and res["max_over_ranks"] == float(world)
+    assert res["query_seeds"] == [1000 + r_ for r_ in range(world)] and len(set(res["query_seeds"])) == world
+    assert abs(res["value"] * 1e6 * res["ms_per_step"] / 1e3 - world * res["batch"]) < 1e-6 * world * res["batch"]
+    assert res["collective"]["backend"] == "gloo" and res["collective"]["world_size"] == world
+
+
 def test_bench_gpus_n_fails_loudly_without_n_gpus():
     """with the RCCL backend and fewer than N visible GPUs the launcher must exit non-zero with a clear message,
     never fall back to one rank silently"""

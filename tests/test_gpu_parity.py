@@ -118,8 +118,8 @@ def test_yeast_validate_self_and_oracle_parity(yeast, w, skew):  # kphf/mod.rs:1
                                            (31, 31, M.MZ_NO_SKEW_INDEX, 7), (27, 1, 16, 8)])
 def test_random_unitig_sets_match_oracle(k, w, skew, seed):
     codes, starts = H.random_unitigs(seed, 400, 150 if k > 9 else 3, k, max_len=800)
-    if k <= 9:  # small k: random sequence repeats k-mers; the tie rule is out of the parity contract -> dedupe
-        pytest.skip("duplicate k-mers by construction") if k < 5 else None
+    # (small k: random sequence repeats k-mers; which occurrence answers is out of the parity contract, so the branch for sets
+    # with duplicates below compares hit / miss with the dictionary and lets validate_self count the duplicates)
     words = H.pack_codes(codes)
     total = int(starts[-1])
     orc = O.OracleSSHash(words, total, starts, k, w, skew, seed)
