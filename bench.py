@@ -29,9 +29,11 @@ B_ALG_OWN = {True: 178.0, False: 122.0}  # same accounting for this repository's
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, 8.0 TB/s spec
 
 DEFAULT_BATCH = {"s-tiny": 200_000, "s-yeast": 10_000_000, "s-txome": 50_000_000, "s-eighth": 50_000_000, "s-human": 125_000_000,
-                 "s-pan": 125_000_000}
+                 "s-pan": 125_000_000, "s-human-rep": 125_000_000, "s-eighth-rep": 50_000_000, "s-tiny-rep": 200_000}
 SHAPE = {"s-human": "GRCh38-shaped", "s-pan": "pan-genome-shaped (120 M unitigs, 9 Gbp)", "s-eighth": "GRCh38/8-shaped",
-         "s-yeast": "yeast-sized", "s-txome": "transcriptome-shaped", "s-tiny": "tiny"}
+         "s-yeast": "yeast-sized", "s-txome": "transcriptome-shaped", "s-tiny": "tiny",
+         "s-human-rep": "GRCh38-shaped, repeat families (8 % of the sequence, 300 bp, 5-15 % divergence)",
+         "s-eighth-rep": "GRCh38/8-shaped, repeat families", "s-tiny-rep": "tiny, repeat families"}
 
 
 def log(msg):
@@ -288,6 +290,36 @@ def bench_projection(ix, us, d_recs, n, dev, torch, np, steps=5):
         lib.mz_u2pos_free(u)
 
 
+# ------------------------------------------------------------------------------------------------ realistic skew (side line)
+def bench_realistic_skew(args, batch, dev, synth, torch, workload="s-human-rep"):
+    """point-query rates and the layout statistics of the repeat-family variant of the headline set (built, validated and freed here)"""
+    t0 = time.time()
+    us2 = synth.make_unitig_set(workload, k=31, device=dev)
+    ix2, rep, rebuilds = synth.build_index_unique(us2, args.w, args.skew, args.seed, device=dev.index, on_device=not args.host_build)
+    st = ix2.line_stats()
+    out = torch.empty(batch * 2, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(3, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    rates = {}
+    for name, kw in (("neg_u_50_50", {}), ("neg_1_50_50", dict(neg_kind="sub1")), ("positives_only", dict(neg_frac=0.0))):
+        q2 = synth.make_query_mix(ix2, us2, batch, seed=3000, device=dev, **kw)
+        ix2.k2u_batch_device(q2, out, cnt, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(5):
+            ix2.k2u_batch_device(q2, out, cnt, stream.cuda_stream)
+        b.record(stream)
+        torch.cuda.synchronize(dev)
+        rates[name] = round(batch * 5 / (a.elapsed_time(b) / 1e3) / 1e6, 2)
+        del q2
+    return {"workload": f"{workload}: {SHAPE[workload]}; {us2['rep_substitutions']} bases substituted so that no 31-mer of a copy repeats",
+            "M_kmers_per_s_one_gpu": rates, "validate_self": rep, "n_kmers": ix2.n_kmers(), "index_hbm_gb": round(ix2.device_bytes() / 1e9, 3),
+            "lines": {"g": st["g"], "t": st["t"], "entries_per_line": round(st["entries_per_line"], 3), "frac_inline": round(st["frac_inline"], 4),
+                      "frac_spilled": round(st["frac_spilled"], 4), "frac_heavy": round(st["frac_heavy"], 4)},
+            "seconds": round(time.time() - t0, 1)}
+
+
 # ------------------------------------------------------------------------------------------------ reads mode
 def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
     """BASELINE config 3: reads -> every k-mer window, results identical to independent k2u calls"""
@@ -493,7 +525,9 @@ def main():
                          "algorithmic_bytes_per_kmer": B_ALG},
             "timed_region_s": round(elapsed, 4), "collective": collective_info(backend, n_gpus),
             "build": {"gen_s": round(t_gen, 2), "where": "host" if args.host_build else "gpu", "build_and_validate_s": round(t_build, 2),
-                      "rebuilds_for_duplicates": rebuilds, "bits_per_kmer": round(ix.num_bits() / ix.n_kmers(), 2)},
+                      "rebuilds_for_duplicates": rebuilds, "bits_per_kmer": round(ix.num_bits() / ix.n_kmers(), 2),
+                      "lines": {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in ix.line_stats().items()
+                                if kk in ("g", "t", "entries_per_line", "frac_inline", "frac_spilled", "frac_heavy")}},
         }
         if validate is not None:
             res["validate_self"] = validate
@@ -517,6 +551,10 @@ def main():
             res["mixes_M_kmers_per_s_one_gpu"] = mixes
             step()  # `out` holds the headline batch's results again for the parity check below
             torch.cuda.synchronize(dev)
+        if n_gpus == 1 and not args.no_extra_mixes and args.workload == "s-human":
+            # a side line, never the headline: the same shape with the repeat model of the configuration's description (repeat families with
+            # per-copy divergence: bucket sizes form a continuum) instead of planted 16-mers -- does the layout hold up there?
+            res["realistic_skew"] = bench_realistic_skew(args, batch, dev, synth, torch)
         if n_gpus == 1 and not args.no_extra_mixes:
             # the step after k2u (get_ref_pos: PiscemUnitigTable occurrences -> MappedRefPos, src/index.rs:156-216) on the headline batch's
             # records: a synthetic tiling in which every unitig occurs once, occurrences packed into the minimal number of bits

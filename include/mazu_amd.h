@@ -176,6 +176,20 @@ uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix);
  * (sized by the entries: at most 3, else 5, else 10 per line of 16 slots) stays within max(64 MiB, 64 bytes per entry,
  * min(9 GiB, 1 KiB per entry)); mz_build_opts.minimizer_lines / lines_max_load decide otherwise. */
 uint32_t mz_sshash_has_minimizer_lines(const mz_sshash *ix);
+/* what the minimizer lines hold (this layout's part of print_stats, sshash.rs:360-395): where the bucket entries of the index are answered from.
+ * All zero for an index without lines.  Counted on the GPU (the index is placed on device 0 if it is nowhere yet). */
+typedef struct mz_line_stats {
+    uint64_t n_lines;         /* 128-byte lines of 16 slots */
+    uint32_t g, t;            /* a minimizer word = tag (t bits) | line index | low (g bits) */
+    uint64_t entries_total;   /* bucket entries of the index (n_minimizer_occs) */
+    uint64_t entries_inline;  /* ... copied into their key's line: answered by the line gather alone */
+    uint64_t buckets_spilled; /* light buckets that did not fit their line ... */
+    uint64_t entries_spilled; /* ... and their entries: one more dependent access into the entry array */
+    uint64_t buckets_heavy;   /* buckets beyond skew_param: answered by the skew index */
+    uint64_t entries_heavy;
+    uint64_t slots_empty;
+} mz_line_stats;
+int mz_sshash_line_stats(mz_sshash *ix, mz_line_stats *out);
 /* bytes resident in HBM once uploaded */
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix);
 

@@ -37,6 +37,12 @@ class QueryOpts(C.Structure):  # mz_query_opts
                 ("reads_kernel", C.c_int32), ("reads_verify", C.c_int32), ("reads_grid", C.c_int32)]
 
 
+class LineStats(C.Structure):  # mz_line_stats
+    _fields_ = [("n_lines", C.c_uint64), ("g", C.c_uint32), ("t", C.c_uint32), ("entries_total", C.c_uint64), ("entries_inline", C.c_uint64),
+                ("buckets_spilled", C.c_uint64), ("entries_spilled", C.c_uint64), ("buckets_heavy", C.c_uint64), ("entries_heavy", C.c_uint64),
+                ("slots_empty", C.c_uint64)]
+
+
 class ValidateReport(C.Structure):
     _fields_ = [("n_kmers", C.c_uint64), ("n_fail", C.c_uint64), ("n_duplicate", C.c_uint64), ("first_fail_pos", C.c_uint64)]
 
@@ -90,6 +96,7 @@ def _load():
         "mz_sshash_num_bits": (u64, [p]),
         "mz_sshash_minimizer_mphf_kind": (u32, [p]),
         "mz_sshash_has_minimizer_lines": (u32, [p]),
+        "mz_sshash_line_stats": (i, [p, p]),
         "mz_sshash_device_bytes": (u64, [p]),
         "mz_sshash_to_device": (i, [p, i]),
         "mz_sshash_k2u": (i, [p, u64, u32, p]),

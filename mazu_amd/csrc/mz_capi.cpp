@@ -701,6 +701,31 @@ int mz_sshash_validate_self_duplicates(mz_sshash *ix, mz_validate_report *report
 }
 int mz_sshash_validate_self(mz_sshash *ix, mz_validate_report *report) { return mz_sshash_validate_self_duplicates(ix, report, nullptr, 0, nullptr); }
 
+int mz_sshash_line_stats(mz_sshash *ix, mz_line_stats *out) {
+    if (!ix || !out) { set_error("null argument"); return MZ_EINVAL; }
+    std::memset(out, 0, sizeof(*out));
+    if (!ix->host.front.present) return MZ_OK;
+    DeviceGuard guard;
+    int rc = ensure_device(ix);
+    if (rc != MZ_OK) return rc;
+    HIPC(hipSetDevice(ix->dev->device));
+    uint64_t *d = nullptr;
+    HIPC(hipMalloc((void **)&d, 6 * 8));
+    uint64_t h[6] = {0, 0, 0, 0, 0, 0};
+    hipError_t e = hipMemset(d, 0, 6 * 8);
+    if (e == hipSuccess) { rc = launch_line_stats(*ix->dev, d, nullptr); e = hipMemcpy(h, d, 6 * 8, hipMemcpyDeviceToHost); }
+    (void)hipFree(d);
+    if (rc != MZ_OK) return rc;
+    if (e != hipSuccess) { set_error("HIP error %d (%s) in mz_sshash_line_stats", (int)e, hipGetErrorString(e)); return MZ_EHIP; }
+    out->n_lines = ix->dev->view.front.n_lines;
+    out->g = ix->host.front.g; out->t = ix->host.front.t;
+    out->entries_total = ix->host.pos.n;
+    out->entries_inline = h[0]; out->buckets_spilled = h[1]; out->entries_spilled = h[2]; out->buckets_heavy = h[3];
+    out->entries_heavy = ix->host.pos.n - h[0] - h[2]; // (a heavy marker's own count saturates at 65535: what is neither inline nor spilled is heavy)
+    out->slots_empty = h[5];
+    return MZ_OK;
+}
+
 int mz_sshash_extract_kmers_device(mz_sshash *ix, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
                                    uint64_t *d_fw_words, void *stream) {
     DeviceGuard guard;

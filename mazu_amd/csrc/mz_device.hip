@@ -2027,6 +2027,27 @@ __global__ __launch_bounds__(kBlock, 4) void validate_self_kernel(IndexView ix, 
     }
 }
 
+// what the minimizer lines hold, by slot kind (the layout's own print_stats, cf. sshash.rs:360-395): out[0] entries inline,
+// [1] buckets behind a spill marker, [2] their entries, [3] heavy buckets, [4] their entries (a marker's count saturates at
+// 65535), [5] empty slots
+__global__ __launch_bounds__(kBlock) void line_stats_kernel(const uint64_t *__restrict__ lines, uint64_t n_slots, unsigned long long *out) {
+    unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_slots; i += stride) {
+        const uint64_t e = lines[i];
+        const uint32_t kind = (uint32_t)e & 3u, cnt = (uint32_t)(e >> kFrontFlankShift) & 0xFFFFu;
+        c[0] += kind == kFrontEntry;
+        c[1] += kind == kFrontSpill; c[2] += kind == kFrontSpill ? cnt : 0u;
+        c[3] += kind == kFrontHeavy; c[4] += kind == kFrontHeavy ? cnt : 0u;
+        c[5] += kind == kFrontEmptyKind;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        for (int off = 32; off > 0; off >>= 1) c[j] += __shfl_down(c[j], off);
+        if ((threadIdx.x & 63) == 0 && c[j]) atomicAdd(&out[j], c[j]);
+    }
+}
+
 // forward words at given global positions (positive-query synthesis, stays in HBM)
 __global__ __launch_bounds__(kBlock) void extract_kmers_kernel(IndexView ix, const uint64_t *__restrict__ positions,
                                                                const uint8_t *__restrict__ flip, uint64_t n,
@@ -2234,6 +2255,14 @@ int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, uint64_t *d_d
     else
         hipLaunchKernelGGL(validate_self_kernel<0>, dim3(tile_grid(d, n_tiles, 16)), dim3(kBlock), 0, stream, d.view,
                            (unsigned long long *)d_report, (unsigned long long *)d_dup_list, dup_cap);
+    MZ_HIP_CHECK(hipGetLastError());
+    return MZ_OK;
+}
+
+int launch_line_stats(const DeviceIndex &d, uint64_t *d_out, hipStream_t stream) {
+    MZ_HIP_CHECK(hipSetDevice(d.device));
+    const uint64_t n_slots = d.view.front.lines ? d.view.front.n_lines * kFrontSlots : 0;
+    if (n_slots) hipLaunchKernelGGL(line_stats_kernel, dim3(grid_for(d, n_slots, 16)), dim3(kBlock), 0, stream, d.view.front.lines, n_slots, (unsigned long long *)d_out);
     MZ_HIP_CHECK(hipGetLastError());
     return MZ_OK;
 }

@@ -220,6 +220,16 @@ class SSHash:  # sshash.rs:39-51
     def minimizer_mphf_kind(self): return lib.mz_sshash_minimizer_mphf_kind(self._h)
     def has_minimizer_lines(self): return bool(lib.mz_sshash_has_minimizer_lines(self._h))
     def device_bytes(self): return lib.mz_sshash_device_bytes(self._h)
+
+    def line_stats(self):
+        """where the bucket entries are answered from (mz_line_stats), plus the fractions of the entry mass"""
+        o = _capi.LineStats()
+        check(lib.mz_sshash_line_stats(self._h, C.byref(o)))
+        d = {f: getattr(o, f) for f, _ in _capi.LineStats._fields_}
+        tot = max(1, d["entries_total"])
+        d.update(frac_inline=d["entries_inline"] / tot, frac_spilled=d["entries_spilled"] / tot, frac_heavy=d["entries_heavy"] / tot,
+                 entries_per_line=d["entries_total"] / max(1, d["n_lines"]))
+        return d
     def to_device(self, device=0): check(lib.mz_sshash_to_device(self._h, device))
 
     def k2u(self, km):

@@ -28,6 +28,16 @@ PRESETS = {
     "s-human": dict(n_unitigs=36145130, mean_extra=68.8, cap=33414 - 31, plant_frac=0.08, n_families=16384, total_len=3_589_802_592),
     # pan-genome scale (an assumption: no in-tree figure exists): 120 M unitigs, 9 Gbp
     "s-pan": dict(n_unitigs=120_000_000, mean_extra=44.5, cap=33414 - 31, plant_frac=0.08, n_families=32768, total_len=9_000_000_000),
+    # the same shapes with REPEAT FAMILIES instead of planted 16-mers (see _plant_repeat_families): 8 % of the sequence are copies of
+    # 300-base family consensus sequences, each copy with its own 5-15 % of substituted bases, ~480 copies per family.  The minimizers
+    # inside the copies get buckets of every size from one to hundreds of entries -- a continuum, where the planted 16-mers give
+    # buckets of ~3 or ~1000.
+    "s-human-rep": dict(n_unitigs=36145130, mean_extra=68.8, cap=33414 - 31, plant_frac=0.0, n_families=0, total_len=3_589_802_592,
+                        rep_frac=0.08, rep_families=2000, rep_len=300, rep_div=(0.05, 0.15)),
+    "s-eighth-rep": dict(n_unitigs=36145130 // 8, mean_extra=68.8, cap=33414 - 31, plant_frac=0.0, n_families=0, total_len=3_589_802_592 // 8,
+                         rep_frac=0.08, rep_families=250, rep_len=300, rep_div=(0.05, 0.15)),
+    "s-tiny-rep": dict(n_unitigs=300, mean_extra=400.0, cap=5000, plant_frac=0.0, n_families=0, total_len=None,
+                       rep_frac=0.08, rep_families=2, rep_len=300, rep_div=(0.05, 0.15)),
 }
 
 
@@ -105,7 +115,98 @@ def make_unitig_set(preset, k=31, seed=0x6D617A75, device="cpu", total_len=None)
     if L & 31:
         keep = (1 << (2 * (L & 31))) - 1
         words[nw - 1] &= keep
-    return dict(words=words, starts=starts, total_len=L, n_unitigs=n, k=k, preset=preset if isinstance(preset, str) else "custom")
+    n_rep_sub = _plant_repeat_families(words, L, k, p, g, dev) if p.get("rep_frac") else 0
+    return dict(words=words, starts=starts, total_len=L, n_unitigs=n, k=k, preset=preset if isinstance(preset, str) else "custom",
+                rep_substitutions=n_rep_sub)
+
+
+_M62 = (1 << 62) - 1
+
+
+def kmer_words_at(words, pos, k=31):
+    """forward 2-bit words of the k-mers (k <= 31) starting at global positions `pos` (int64 tensor) of a packed sequence"""
+    wi, sh = pos >> 5, (pos & 31) * 2
+    lo, hi = words[wi], words[wi + 1]
+    zero = sh == 0
+    a = (lo >> sh) & torch.where(zero, torch.full_like(sh, -1), (torch.ones_like(sh) << (64 - sh).clamp(max=62)) - 1)
+    b = torch.where(zero, torch.zeros_like(hi), hi << (64 - sh).clamp(max=63))
+    return (a | b) & ((1 << (2 * k)) - 1)
+
+
+def kmer_rc_words(x, k=31):
+    """reverse complements of 2-bit k-mer words (int64 tensor, k <= 31)"""
+    y = ~x
+    for s_, m in ((2, 0x3333333333333333), (4, 0x0F0F0F0F0F0F0F0F), (8, 0x00FF00FF00FF00FF), (16, 0x0000FFFF0000FFFF), (32, 0x00000000FFFFFFFF)):
+        y = ((y >> s_) & m) | ((y & m) << s_)
+    return (y >> (64 - 2 * k)) & ((1 << (2 * k)) - 1)
+
+
+def _add_codes(words, pos, new_codes):
+    """set the 2-bit codes at the (distinct) global positions `pos`: every field changes by (new - old) << shift, summed exactly"""
+    wi, sh = pos >> 5, (pos & 31) * 2
+    old = (words[wi] >> sh) & 3
+    words.index_add_(0, wi, (new_codes - old) << sh)
+
+
+def _plant_repeat_families(words, L, k, p, g, dev):
+    """Repeat families as in a genome's interspersed repeats: `rep_families` random consensus sequences of `rep_len` bases; copies
+    fill `rep_frac` of the sequence at distinct slots, every copy with its own substitution rate drawn from `rep_div` and its own
+    random substitutions.  Copies of one family share many 15-mers (the minimizers inside them own buckets of every size) and, at
+    first, also 31-mers -- which a cdBG cannot contain twice.  Those are removed here on the device: the canonical 31-mers of all
+    windows that touch a copy are sorted, and in every stretch shared by two copies bases are substituted, one per 16 positions
+    (enough to make each 31-base window differ), until no window of a copy repeats.  Returns the number of bases substituted."""
+    rep_len, n_fam = int(p["rep_len"]), int(p["rep_families"])
+    n_slots = (L - 2 * k) // rep_len
+    n_copies = min(int(p["rep_frac"] * L / rep_len), n_slots)
+    if n_copies <= 0 or n_fam <= 0:
+        return 0
+    cons = torch.randint(0, 4, (n_fam, rep_len), generator=g, device=dev, dtype=torch.int64)
+    slot = torch.randperm(n_slots, generator=g, device=dev)[:n_copies]
+    start = slot * rep_len + k  # (the first k bases of the sequence stay background)
+    fam = torch.randint(0, n_fam, (n_copies,), generator=g, device=dev)
+    lo_d, hi_d = p["rep_div"]
+    n_sub_total = 0
+    chunk = max(1, (64 << 20) // rep_len)  # copies per pass: bounded temporaries
+    for a in range(0, n_copies, chunk):
+        st, fm = start[a:a + chunk], fam[a:a + chunk]
+        div = lo_d + (hi_d - lo_d) * torch.rand(st.numel(), generator=g, device=dev)
+        sub = torch.rand(st.numel(), rep_len, generator=g, device=dev) < div[:, None]
+        shift = torch.randint(1, 4, (st.numel(), rep_len), generator=g, device=dev, dtype=torch.int64)
+        codes = torch.where(sub, (cons[fm] + shift) & 3, cons[fm])
+        pos = st[:, None] + torch.arange(rep_len, device=dev)[None, :]
+        _add_codes(words, pos.reshape(-1), codes.reshape(-1))
+        del div, sub, shift, codes, pos
+    # ---- no 31-mer of a copy may occur twice
+    win = torch.arange(-(k - 1), rep_len, device=dev)  # windows that touch a copy
+    for rnd in range(16):
+        # all windows at once would be 330 x n_copies words; the sort needs them together (duplicates pair ACROSS copies)
+        pos = torch.unique((start[:, None] + win[None, :]).reshape(-1))  # (the windows of neighbouring slots overlap)
+        pos = pos[pos <= L - k]
+        fw = kmer_words_at(words, pos, k)
+        canon = torch.minimum(fw, kmer_rc_words(fw, k))
+        del fw
+        srt, order = torch.sort(canon)
+        del canon
+        eq = srt[1:] == srt[:-1]
+        del srt
+        later = pos[order[1:][eq]]  # every occurrence but the first of its sorted run
+        del order, eq, pos
+        n_dup = int(later.numel())
+        if n_dup == 0:
+            break
+        # one substitution per 16 positions of a shared stretch breaks every 31-base window of it; after a few rounds, whatever is left
+        pick = later if rnd >= 6 else later[(later & 15) == ((5 * rnd) & 15)]
+        if pick.numel() == 0:
+            continue
+        # (late rounds: at a random base of the window -- by then the copies of a family may carry all four bases at a window's middle)
+        tgt = torch.unique(pick + (k // 2 if rnd < 6 else torch.randint(0, k, (pick.numel(),), generator=g, device=dev)))
+        old = (words[tgt >> 5] >> ((tgt & 31) * 2)) & 3
+        _add_codes(words, tgt, (old + torch.randint(1, 4, (tgt.numel(),), generator=g, device=dev, dtype=torch.int64)) & 3)  # (drawn per copy: copies must part ways)
+        n_sub_total += int(tgt.numel())
+        del later, pick, tgt, old
+    else:
+        raise AssertionError("repeat copies still share 31-mers after 16 rounds")
+    return n_sub_total
 
 
 def mutate_positions(us, positions):

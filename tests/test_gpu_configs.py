@@ -71,6 +71,46 @@ def test_s_eighth_headline_kernel_matches_oracle(front):
     assert abs(n_hit - 1_200_000) <= 8  # positives hit; NEG-U / NEG-1 negatives miss (up to accidental members)
 
 
+def test_s_eighth_rep_realistic_skew_matches_oracle():
+    """BASELINE configs[3] at 1/8 scale with the repeat model its description asks for: 8 % of the sequence are copies of 300-base
+    repeat families at 5-15 % per-copy divergence (synth._plant_repeat_families), so bucket sizes form a continuum from one to
+    hundreds of entries instead of the two modes of the planted 16-mers.  Layout by the size rules; 2 M NEG-U + 200 k NEG-1
+    queries byte-identical to the oracle; the line statistics must show the continuum (inline, spilled AND heavy mass)."""
+    import torch
+    from mazu_amd import synth
+    us = synth.make_unitig_set("s-eighth-rep", device="cuda")
+    assert us["total_len"] == 3_589_802_592 // 8 and us["rep_substitutions"] > 100_000  # copies shared 31-mers before the de-duplication
+    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
+    assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and rep["n_kmers"] == ix.n_kmers()
+    assert ix.minimizer_mphf_kind() == 1 and ix.has_minimizer_lines() and ix.n_kmers_in_skew_index() > 0
+    st = ix.line_stats()
+    _log(f"s-eighth-rep lines: {st}")
+    assert st["entries_inline"] + st["entries_spilled"] + st["entries_heavy"] == st["entries_total"] == ix.n_minimizer_occs()
+    assert st["frac_inline"] > 0.9 and st["buckets_spilled"] > 1000 and st["buckets_heavy"] > 1000
+    q = synth.make_query_mix(ix, us, 2_000_000, seed=11, device="cuda")                         # 50/50 NEG-U
+    q1 = synth.make_query_mix(ix, us, 400_000, seed=12, device="cuda", neg_kind="sub1")        # 200 k positives + 200 k NEG-1
+    qq = torch.cat([q, q1])
+    out, (n_hit, n_miss, _) = _k2u_device(ix, qq)
+    words, starts = _host_arrays(us)
+    orc = O.OracleSSHash(words, us["total_len"], starts, 31, 15, 32, with_dict=False)
+    want, o_hit = orc.k2u_batch(qq.cpu().numpy().view(np.uint64), n_threads=M.lib.mz_host_threads())
+    got = out.cpu().numpy().view(M.K2UPOS_DTYPE)
+    assert got.tobytes() == want.tobytes()
+    # (a k-mer of a repeat copy with one base substituted is, now and then, the k-mer of another copy: a few NEG-1 queries hit, here and in the oracle)
+    assert (n_hit, n_miss) == (o_hit, qq.numel() - o_hit) and 1_200_000 <= n_hit <= 1_202_000
+    # reads over the repeats: windows inside copies meet the large buckets
+    bases, ro = synth.make_reads(us, 20_000, 150, seed=2000, device="cuda")
+    ko = synth.kmer_offsets(ro, 31)
+    want_r, _, oc = orc.k2u_reads(bases.cpu().numpy(), ro.cpu().numpy().astype(np.uint64), streaming=True)
+    for verify in ("each", "group"):
+        ix.set_query_opts(reads_verify=verify)
+        out_r = torch.zeros(int(ko[-1]) * 2, dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(3, dtype=torch.int64, device="cuda")
+        ix.k2u_reads_device(bases, ro, ko, out_r, cnt, streaming=True, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert out_r.cpu().numpy().view(M.K2UPOS_DTYPE).tobytes() == want_r.tobytes() and cnt.cpu().tolist() == oc.tolist(), verify
+
+
 @pytest.mark.parametrize("bytes_per_key,kind,reads_lines,resolve,verify", [(48, 1, None, None, None), (48, 1, "lines", "run", None), (48, 1, "lines", "item", None),
                                                                             (16, 0, None, None, None), (48, 1, None, None, "group"), (48, 1, "lines", "item", "group")])
 def test_s_txome_reads_match_oracle_streaming_walk(bytes_per_key, kind, reads_lines, resolve, verify):
