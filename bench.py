@@ -60,6 +60,8 @@ def parse_args(argv=None):
                     help="skip the correctness gate (K2U::validate_self on the device, every k-mer in both orientations) before timing")
     ap.add_argument("--no-build-check", dest="build_check", action="store_false",
                     help="do not validate the index after the build either (stage-cost experiments with kernel variants whose results are meaningless)")
+    ap.add_argument("--lines", default="auto", choices=["auto", "on", "off"],
+                    help="minimizer lines: by the size rule, forced, or never built (mz_build_opts.minimizer_lines); off measures the MPHF path alone")
     ap.add_argument("--host-build", action="store_true", help="build the index with the multi-threaded host builder instead of on the GPU")
     ap.add_argument("--mode", default="kmers", choices=["kmers", "reads"],
                     help="kmers: batched point queries (headline); reads: BASELINE config 3, every window of 150-bp reads "
@@ -448,7 +450,8 @@ def main():
     # host builder); duplicate 31-mers of the random background (a handful at this scale) are broken up and the index rebuilt,
     # so K2U::validate_self holds with no duplicate at all
     ix, validate, rebuilds = synth.build_index_unique(us, args.w, args.skew, args.seed, device=dev_index, on_device=not args.host_build,
-                                                      log=log if rank == 0 else None, check=args.build_check)
+                                                      log=log if rank == 0 else None, check=args.build_check,
+                                                      minimizer_lines={"auto": 0, "on": 1, "off": -1}[args.lines])
     torch.cuda.synchronize(dev)
     t_build = time.time() - t0
     words_h = us["words"].cpu().numpy().view(np.uint64)
@@ -524,7 +527,7 @@ def main():
                          "kernel": {3: "k2u_batch_kernel", 2: "k2u_tile_kernel"}.get(ix.get_query_opts()["point_kernel"], "k2u_wave_kernel"), "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_kmer": B_ALG},
             "timed_region_s": round(elapsed, 4), "collective": collective_info(backend, n_gpus),
-            "build": {"gen_s": round(t_gen, 2), "where": "host" if args.host_build else "gpu", "build_and_validate_s": round(t_build, 2),
+            "build": {"gen_s": round(t_gen, 2), "where": "host" if args.host_build or 2 * args.w > 32 else "gpu",  # (the GPU builder hands minimizers beyond 32 bits to the host builder) "build_and_validate_s": round(t_build, 2),
                       "rebuilds_for_duplicates": rebuilds, "bits_per_kmer": round(ix.num_bits() / ix.n_kmers(), 2),
                       "lines": {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in ix.line_stats().items()
                                 if kk in ("g", "t", "entries_per_line", "frac_inline", "frac_spilled", "frac_heavy")}},

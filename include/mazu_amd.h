@@ -172,9 +172,11 @@ uint64_t mz_sshash_num_bits(const mz_sshash *ix);
  * the record table within max(64 MiB, 48 bytes per key, min(1 GiB, 1 KiB per key))), 0 = BBHash levels */
 uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix);
 /* 1 when the index carries minimizer lines: membership and the entries of most buckets (sshash.rs:478-495: MPHF probe, two
- * Elias-Fano offsets, position array) answered by one 128-byte gather.  Built for direct-address minimizers when the table
- * (sized by the entries: at most 3, else 5, else 10 per line of 16 slots) stays within max(64 MiB, 64 bytes per entry,
- * min(9 GiB, 1 KiB per entry)); mz_build_opts.minimizer_lines / lines_max_load decide otherwise. */
+ * Elias-Fano offsets, position array) answered by one 128-byte gather.  Built when the table (sized by the entries: at
+ * most 3, else 5, else 10 per line of 16 slots) stays within max(64 MiB, 64 bytes per entry, min(9 GiB, 1 KiB per entry));
+ * mz_build_opts.minimizer_lines / lines_max_load decide otherwise.  2w <= 32: lines addressed by the minimizer word itself
+ * (direct-address minimizers only); 2w > 32: by a hash of the word, beside the BBHash levels, which stay the exact path for
+ * the ~2 % of the lines the builder cannot use (mz_line_stats.lines_unusable) and for reads. */
 uint32_t mz_sshash_has_minimizer_lines(const mz_sshash *ix);
 /* what the minimizer lines hold (this layout's part of print_stats, sshash.rs:360-395): where the bucket entries of the index are answered from.
  * All zero for an index without lines.  Counted on the GPU (the index is placed on device 0 if it is nowhere yet). */
@@ -188,6 +190,8 @@ typedef struct mz_line_stats {
     uint64_t buckets_heavy;   /* buckets beyond skew_param: answered by the skew index */
     uint64_t entries_heavy;
     uint64_t slots_empty;
+    uint64_t lines_unusable;  /* 2w > 32 only (lines addressed by a hash of the word, g = 0, t = log2 n_lines): lines given up because two of */
+    uint64_t entries_unusable; /* their words share a fingerprint or more than 16 words fell into them; their queries take the MPHF path */
 } mz_line_stats;
 int mz_sshash_line_stats(mz_sshash *ix, mz_line_stats *out);
 /* bytes resident in HBM once uploaded */

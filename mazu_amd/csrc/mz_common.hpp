@@ -398,7 +398,7 @@ constexpr uint32_t kFrontKeyMask = ((1u << kFrontKeyBits) - 1) << kFrontKeyShift
 struct FrontView {
     const uint64_t *lines; // n_lines * 16 slots; nullptr: the index has no minimizer lines
     uint64_t n_lines;      // 2^L
-    uint32_t g, t;
+    uint32_t g, t;         // (2w > 32, lines addressed by front_hash of the word: g = 0, t = L)
 };
 MZ_HD uint64_t front_line_of(uint32_t key, uint32_t g, uint64_t n_lines) { return (uint64_t)(key >> g) & (n_lines - 1); }
 // low | tag << g of a word; gl = g + L (<= 32)
@@ -495,36 +495,28 @@ MZ_HD uint32_t front_line_members(const uint64_t *minrec, uint32_t g, uint64_t g
     bucket0 = (hdr & kMinRecRankMask) + (hdr >> 40) + popc64(wv & ~(~0ull << bi));
     return (uint32_t)((wv >> bi) & ((1ull << (1u << g)) - 1)); // 2^g <= 16 keys never straddle a bitmap word
 }
-// Packs line `line` of a table with 2^line_bits lines.  minrec: the minimizer records (membership and bucket ids of the
-// 2^t groups of 2^g words that share the line); psum: bucket starts; entries: the entry array (`pos` layout).  Light buckets
+// Minimizer lines for w-mers of more than 32 bits (2w > 32).  The words cannot address the table, so a HASH of the word does:
+// line = low bits of front_hash(word), and the slot's key field carries 8 more bits of the hash.  The fingerprint is not the key,
+// so the builder keeps the table exact another way: a line in which two member words share a fingerprint, or that more than 16
+// member words hash to, is not used at all -- its first slot is kFrontUnusable and a query that meets it takes the exact walk
+// through the MPHF (about 2 % of the lines at a mean of 2 entries per line).  In every other line each member word owns slots
+// under a fingerprint of its own, so "no slot with my fingerprint" means "not a minimizer of the set", and a foreign word that
+// happens to share a member's fingerprint is caught like every false candidate: by the flanks, then by the sequence.
+constexpr uint64_t kFrontHashSeed = 0x6d617a755f66726full;
+MZ_HD uint64_t front_hash(uint64_t word) { const uint64_t h = mum(word ^ kFrontHashSeed, kP3); return h ^ (h >> 29); }
+MZ_HD bool front_is_hashed(uint32_t w) { return 2 * w > 32; }
+MZ_HD uint64_t front_hashed_line(uint64_t h, uint64_t n_lines) { return h & (n_lines - 1); }
+MZ_HD uint32_t front_hashed_keyfield(uint64_t h) { return (uint32_t)(h >> 56); }
+constexpr uint64_t kFrontUnusable = ((uint64_t)0x100u << kFrontKeyShift) | kFrontSpill; // key field 0x100: no query shows it
+// Packs the m <= 16 member keys of one line (key field, first entry and size of each bucket) into its 16 slots.  Light buckets
 // are taken inline in order of increasing size (ties: member order) while every bucket left out still keeps one slot for
-// its marker.  Returns false, with the line left empty, when more than 16 member keys share the line.
-MZ_HD bool front_build_line(uint32_t g, uint32_t t, uint32_t line_bits, uint64_t line, const uint64_t *minrec, const uint64_t *psum,
-                            const uint64_t *entries, uint64_t skew_param, uint64_t *out) {
-    uint32_t keyfield[kFrontSlots], size_c[kFrontSlots];
-    uint64_t first[kFrontSlots], size[kFrontSlots];
+// its marker.
+MZ_HD void front_pack_line(uint32_t m, const uint32_t *keyfield, const uint64_t *first, const uint64_t *size, const uint64_t *entries, uint64_t skew_param, uint64_t *out) {
+    uint32_t size_c[kFrontSlots];
     bool inl[kFrontSlots];
-    uint32_t m = 0;
-    bool overfull = false;
-    for (uint32_t tag = 0; tag < (1u << t) && !overfull; ++tag) {
-        uint64_t bucket0;
-        const uint32_t member_bits = front_line_members(minrec, g, line | ((uint64_t)tag << line_bits), bucket0);
-        uint32_t seen = 0;
-        for (uint32_t j = 0; j < (1u << g); ++j)
-            if ((member_bits >> j) & 1) {
-                if (m == kFrontSlots) { overfull = true; break; }
-                keyfield[m] = j | (tag << g);
-                first[m] = psum[bucket0 + seen];
-                size[m] = psum[bucket0 + seen + 1] - first[m];
-                size_c[m] = size[m] > skew_param || size[m] > kFrontSlots ? 0xFFFFFFFFu : (uint32_t)size[m]; // heavy or hopeless: never inline
-                inl[m] = false;
-                ++seen;
-                ++m;
-            }
-    }
-    if (overfull) {
-        for (uint32_t o = 0; o < kFrontSlots; ++o) out[o] = kFrontEmpty;
-        return false;
+    for (uint32_t a = 0; a < m; ++a) {
+        size_c[a] = size[a] > skew_param || size[a] > kFrontSlots ? 0xFFFFFFFFu : (uint32_t)size[a]; // heavy or hopeless: never inline
+        inl[a] = false;
     }
     uint32_t used = m; // one slot per member to begin with
     for (;;) {         // repeatedly take the smallest bucket not yet inline (ties: first member)
@@ -548,6 +540,36 @@ MZ_HD bool front_build_line(uint32_t g, uint32_t t, uint32_t line_bits, uint64_t
         }
     }
     for (; o < kFrontSlots; ++o) out[o] = kFrontEmpty;
+}
+// Packs line `line` of a table with 2^line_bits lines.  minrec: the minimizer records (membership and bucket ids of the
+// 2^t groups of 2^g words that share the line); psum: bucket starts; entries: the entry array (`pos` layout).  Light buckets
+// are taken inline in order of increasing size (ties: member order) while every bucket left out still keeps one slot for
+// its marker.  Returns false, with the line left empty, when more than 16 member keys share the line.
+MZ_HD bool front_build_line(uint32_t g, uint32_t t, uint32_t line_bits, uint64_t line, const uint64_t *minrec, const uint64_t *psum,
+                            const uint64_t *entries, uint64_t skew_param, uint64_t *out) {
+    uint32_t keyfield[kFrontSlots];
+    uint64_t first[kFrontSlots], size[kFrontSlots];
+    uint32_t m = 0;
+    bool overfull = false;
+    for (uint32_t tag = 0; tag < (1u << t) && !overfull; ++tag) {
+        uint64_t bucket0;
+        const uint32_t member_bits = front_line_members(minrec, g, line | ((uint64_t)tag << line_bits), bucket0);
+        uint32_t seen = 0;
+        for (uint32_t j = 0; j < (1u << g); ++j)
+            if ((member_bits >> j) & 1) {
+                if (m == kFrontSlots) { overfull = true; break; }
+                keyfield[m] = j | (tag << g);
+                first[m] = psum[bucket0 + seen];
+                size[m] = psum[bucket0 + seen + 1] - first[m];
+                ++seen;
+                ++m;
+            }
+    }
+    if (overfull) {
+        for (uint32_t o = 0; o < kFrontSlots; ++o) out[o] = kFrontEmpty;
+        return false;
+    }
+    front_pack_line(m, keyfield, first, size, entries, skew_param, out);
     return true;
 }
 // Shape of the table for a key universe of 2^(2w) words and n_occ entries: the fewest lines (a power of two, at least

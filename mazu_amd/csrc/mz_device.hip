@@ -365,9 +365,18 @@ __device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, 
     S.best[i] = kBestNone;
     S.n[i] = valid ? 0u : kNIdle;
     if (lines) {
-        const uint32_t key = (uint32_t)mn.word, g = ix.front.g, gl = 2 * w - ix.front.t; // word = tag | line index | low g bits: tag starts at bit gl
-        const uint32_t pat = (fl << kFrontFlankShift) | (front_keyfield(key, g, gl) << kFrontKeyShift) | (valid ? 0u : kFrontIdleKey); // (an idle slot has key 0: line 0 is always there)
-        S.slot[i] = (uint64_t)((key >> g) & (uint32_t)(ix.front.n_lines - 1)) | ((uint64_t)pat << 32);
+        uint32_t line, kf;
+        if (front_is_hashed(w)) { // 2w > 32: line and key field from a hash of the word
+            const uint64_t h = front_hash(mn.word);
+            line = (uint32_t)front_hashed_line(h, ix.front.n_lines);
+            kf = front_hashed_keyfield(h);
+        } else {
+            const uint32_t key = (uint32_t)mn.word, g = ix.front.g, gl = 2 * w - ix.front.t; // word = tag | line index | low g bits: tag starts at bit gl
+            line = (key >> g) & (uint32_t)(ix.front.n_lines - 1);
+            kf = front_keyfield(key, g, gl);
+        }
+        const uint32_t pat = (fl << kFrontFlankShift) | (kf << kFrontKeyShift) | (valid ? 0u : kFrontIdleKey); // (an idle slot has key 0: line 0 is always there)
+        S.slot[i] = (uint64_t)line | ((uint64_t)pat << 32);
         S.eoff[i] = 3u | kFrontKeyMask | (flank_cover_mask(mn.offset, k - w - mn.offset) << kFrontFlankShift);
     } else {
         S.slot[i] = mn.word;
@@ -381,9 +390,11 @@ __device__ __forceinline__ void tile_set_query(TileLdsT<SC::NT> &S, uint32_t i, 
 __device__ __forceinline__ mz_k2upos front_walk(const IndexView &ix, uint64_t fw, uint64_t rc, uint32_t off_a) {
     const uint32_t k = ix.k, w = ix.w, g = ix.front.g, gl = 2 * w - ix.front.t;
     const uint64_t gs = fw <= rc ? fw : rc;
-    const uint32_t key = (uint32_t)((gs >> (2 * off_a)) & kmer_mask(w));
-    const uint64_t *line = ix.front.lines + (uint64_t)((key >> g) & (uint32_t)(ix.front.n_lines - 1)) * kFrontSlots;
-    const uint32_t pat = (query_flank(gs, off_a, w) << kFrontFlankShift) | (front_keyfield(key, g, gl) << kFrontKeyShift);
+    const uint64_t word = (gs >> (2 * off_a)) & kmer_mask(w);
+    const uint64_t wh = front_hash(word);
+    const uint32_t key = (uint32_t)word;
+    const uint64_t *line = ix.front.lines + (front_is_hashed(w) ? front_hashed_line(wh, ix.front.n_lines) : (uint64_t)((key >> g) & (uint32_t)(ix.front.n_lines - 1))) * kFrontSlots;
+    const uint32_t pat = (query_flank(gs, off_a, w) << kFrontFlankShift) | ((front_is_hashed(w) ? front_hashed_keyfield(wh) : front_keyfield(key, g, gl)) << kFrontKeyShift);
     const uint32_t msk = 3u | kFrontKeyMask | (flank_cover_mask(off_a, k - w - off_a) << kFrontFlankShift);
     uint32_t alive = 0;
 #pragma unroll 1
@@ -501,6 +512,10 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
                     // heavy or spill marker of this key: same key bits, kind 1 or 2 (a key has entries or one marker, never both)
                     const bool m0 = (x0 & (kFrontKeyMask | 3u)) - 1u < 2u, m1 = (x1 & (kFrontKeyMask | 3u)) - 1u < 2u;
                     if (m0 || m1) { marker = true; marker_e = m0 ? e0 : e1; }
+                    if (front_is_hashed(w) && h == 0 && sub == 0 && e0 == kFrontUnusable) { // hash-addressed line the builder gave up: exact walk through the MPHF
+                        S.best[q] = 0;
+                        atomicOr(&S.qinfo[q], kQMulti);
+                    }
                 }
                 if (first) {
                     S.best[q] = first_e;
@@ -2029,20 +2044,22 @@ __global__ __launch_bounds__(kBlock, 4) void validate_self_kernel(IndexView ix, 
 
 // what the minimizer lines hold, by slot kind (the layout's own print_stats, cf. sshash.rs:360-395): out[0] entries inline,
 // [1] buckets behind a spill marker, [2] their entries, [3] heavy buckets, [4] their entries (a marker's count saturates at
-// 65535), [5] empty slots
+// 65535), [5] empty slots, [6] hash-addressed lines the builder gave up (kFrontUnusable)
+constexpr int kLineStatWords = 7;
 __global__ __launch_bounds__(kBlock) void line_stats_kernel(const uint64_t *__restrict__ lines, uint64_t n_slots, unsigned long long *out) {
-    unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long c[kLineStatWords] = {0, 0, 0, 0, 0, 0, 0};
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_slots; i += stride) {
         const uint64_t e = lines[i];
         const uint32_t kind = (uint32_t)e & 3u, cnt = (uint32_t)(e >> kFrontFlankShift) & 0xFFFFu;
         c[0] += kind == kFrontEntry;
-        c[1] += kind == kFrontSpill; c[2] += kind == kFrontSpill ? cnt : 0u;
+        c[1] += kind == kFrontSpill && e != kFrontUnusable; c[2] += kind == kFrontSpill ? cnt : 0u;
+        c[6] += e == kFrontUnusable;
         c[3] += kind == kFrontHeavy; c[4] += kind == kFrontHeavy ? cnt : 0u;
         c[5] += kind == kFrontEmptyKind;
     }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < kLineStatWords; ++j) {
         for (int off = 32; off > 0; off >>= 1) c[j] += __shfl_down(c[j], off);
         if ((threadIdx.x & 63) == 0 && c[j]) atomicAdd(&out[j], c[j]);
     }
@@ -2223,7 +2240,7 @@ int launch_k2u_reads(const DeviceIndex &d, const QueryOpts &opts, const uint8_t 
     // records 32.1; S-human (547 M) 21.2 / 23.4; s-pan (1.2 G) 15.9 / 19.3.  QueryOpts::reads_lines / reads_resolve override.
     IndexView v = d.view;
     const bool use_lines = opts.reads_lines ? opts.reads_lines > 0 : d.n_entries >= (1ull << 28);
-    if (!use_lines && v.mm.direct) v.front.lines = nullptr;
+    if ((!use_lines && v.mm.direct) || front_is_hashed(v.w)) v.front.lines = nullptr; // (hash-addressed lines serve point queries; reads of such an index resolve one MPHF lookup per run)
     const bool grouped = opts.reads_verify == 2; // grouped verify-and-extend (tile_finish_grouped) instead of one sequence-record gather per candidate
 #define MZ_LAUNCH_READS(KERNEL, GRID) hipLaunchKernelGGL(KERNEL, GRID, dim3(kBlock), 0, stream, v, d_bases, n_bases, d_read_offsets, d_kmer_offsets, n_reads, d_out, d_counts)
     if (v.k == 31 && v.w == 15 && opts.reads_kernel != 2) {

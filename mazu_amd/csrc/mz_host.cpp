@@ -774,6 +774,73 @@ void FrontTable::build(const uint64_t *minrec, uint32_t w, uint64_t n_occ, bool 
     g = t = 0;
 }
 
+void FrontTable::build_hashed(const uint64_t *mm_set, const uint64_t *bucket_of, uint64_t n_mm, uint32_t w, uint64_t n_occ, const uint64_t *psum,
+                              const uint64_t *entries, uint64_t skew_param, int n_threads, const BuildOpts &opts) {
+    lines.clear();
+    present = false;
+    g = t = 0;
+    n_unusable = 0;
+    if (!front_is_hashed(w) || opts.minimizer_lines < 0 || n_mm == 0) return;
+    // size: a power of two of lines at a mean load of at most 3 entries (else 5, else 10) within the same budget as the direct tables
+    const uint64_t loads[3] = {3, 5, 10};
+    uint32_t bits = 0;
+    for (int a = 0; a < 3 && !present; ++a) {
+        const uint64_t load = opts.lines_max_load >= 1 ? opts.lines_max_load : opts.minimizer_lines > 0 ? loads[2] : loads[a];
+        bits = 6;
+        while (bits < 32 && n_occ > load * (1ull << bits)) ++bits;
+        present = opts.minimizer_lines > 0 || opts.lines_max_load >= 1 || (kFrontSlots * 8ull << bits) <= front_table_cap(n_occ);
+        if (opts.minimizer_lines > 0 || opts.lines_max_load >= 1) break;
+    }
+    if (!present) return;
+    t = bits;
+    const uint64_t n_lines = 1ull << bits;
+    lines.assign(n_lines * kFrontSlots, kFrontEmpty);
+    // the member words grouped by line, inside a line in word order
+    std::vector<Occ> by(n_mm);
+    {
+        Occ *BY = by.data();
+        parallel_for(n_threads, n_mm, [=](int, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) BY[i] = Occ{front_hashed_line(front_hash(mm_set[i]), n_lines), i};
+        });
+    }
+    sort_occs(by, bits, n_threads);
+    // shards of whole lines
+    const uint64_t n_shards = std::min<uint64_t>((uint64_t)std::max(n_threads, 1) * 64, std::max<uint64_t>(1, n_mm / 4096));
+    std::vector<uint64_t> bounds(n_shards + 1);
+    for (uint64_t sh = 0; sh <= n_shards; ++sh) {
+        uint64_t c = n_mm / n_shards * sh + std::min(sh, n_mm % n_shards);
+        while (c > 0 && c < n_mm && by[c].word == by[c - 1].word) ++c; // a shard starts at the first word of a line
+        bounds[sh] = c;
+    }
+    std::vector<uint64_t> bad((size_t)std::max(n_threads, 1), 0);
+    uint64_t *L = lines.data(), *BAD = bad.data();
+    const Occ *BY = by.data();
+    const uint64_t *BO = bounds.data();
+    parallel_tasks(n_threads, n_shards, [=](int th, uint64_t sh) {
+        uint64_t i = BO[sh];
+        const uint64_t end = BO[sh + 1];
+        while (i < end) {
+            uint64_t j = i;
+            while (j < end && BY[j].word == BY[i].word) ++j;
+            uint64_t *out = L + BY[i].word * kFrontSlots;
+            uint32_t keyfield[kFrontSlots];
+            uint64_t first[kFrontSlots], size[kFrontSlots];
+            bool ok = j - i <= kFrontSlots;
+            for (uint64_t a = i; a < j && ok; ++a) {
+                const uint64_t mi = BY[a].pos, b = bucket_of[mi];
+                keyfield[a - i] = front_hashed_keyfield(front_hash(mm_set[mi]));
+                first[a - i] = psum[b];
+                size[a - i] = psum[b + 1] - psum[b];
+                for (uint64_t c = i; c < a; ++c) ok = ok && keyfield[c - i] != keyfield[a - i]; // two member words under one fingerprint
+            }
+            if (ok) front_pack_line((uint32_t)(j - i), keyfield, first, size, entries, skew_param, out);
+            else { out[0] = kFrontUnusable; ++BAD[th]; }
+            i = j;
+        }
+    });
+    for (uint64_t x : bad) n_unusable += x;
+}
+
 int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads, const BuildOpts &opts_) {
     const BuildOpts opts = opts_.with_env();
     double t0 = now_s();
@@ -937,7 +1004,8 @@ int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param
     }
     pos.assign(posv.data(), n_occ, max_pos, nt);
     phase("EF + minrec + pack");
-    front.build(mm.blocks.data(), w, n_occ, mm.direct != 0, psum.data(), posv.data(), skew_param, nt, opts);
+    if (front_is_hashed(w)) front.build_hashed(mm_set.data(), slot.data(), n_mm, w, n_occ, psum.data(), posv.data(), skew_param, nt, opts);
+    else front.build(mm.blocks.data(), w, n_occ, mm.direct != 0, psum.data(), posv.data(), skew_param, nt, opts);
     phase("minimizer lines");
     build_seconds = now_s() - t0;
     return MZ_OK;
@@ -1084,7 +1152,9 @@ static const char *check_loaded(const SSHashHost &h) {
     }
     if (h.front.present) { // every slot must point inside the entry array / the sequence
         const FrontTable &t = h.front;
-        if (!h.mm.direct || t.g > kFrontMaxG || t.g + t.t > kFrontMaxKeyBits || t.g + t.t > 2 * h.w || t.lines.size() != (1ull << (2 * h.w - t.g - t.t)) * kFrontSlots) return "minimizer lines";
+        if (front_is_hashed(h.w)) {
+            if (h.mm.direct || t.g != 0 || t.t > 32 || t.lines.size() != ((uint64_t)kFrontSlots << t.t)) return "minimizer lines (hashed)";
+        } else if (!h.mm.direct || t.g > kFrontMaxG || t.g + t.t > kFrontMaxKeyBits || t.g + t.t > 2 * h.w || t.lines.size() != (1ull << (2 * h.w - t.g - t.t)) * kFrontSlots) return "minimizer lines";
         for (uint64_t e : t.lines) {
             const uint32_t kind = (uint32_t)e & 3u;
             const uint64_t a = e >> kFrontPosShift;

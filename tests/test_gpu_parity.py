@@ -94,10 +94,15 @@ def yeast():
     return k, seqs
 
 
-@pytest.mark.parametrize("w,skew", [(15, M.MZ_NO_SKEW_INDEX), (15, 32), (15, 16), (11, 8), (20, 2), (31, M.MZ_NO_SKEW_INDEX), (1, 64), (4, M.MZ_NO_SKEW_INDEX)])
+@pytest.mark.parametrize("w,skew", [(15, M.MZ_NO_SKEW_INDEX), (15, 32), (15, 16), (11, 8), (20, 2), (31, M.MZ_NO_SKEW_INDEX), (1, 64), (4, M.MZ_NO_SKEW_INDEX),
+                                    (17, 32), (19, 16), (21, M.MZ_NO_SKEW_INDEX)])
 def test_yeast_validate_self_and_oracle_parity(yeast, w, skew):  # kphf/mod.rs:147-161
     k, seqs = yeast
     ix, orc, (words, total, starts) = both(seqs, k, w, skew)
+    if w > 16:  # minimizer words beyond 32 bits: lines addressed by a hash of the word, the BBHash levels behind the few lines given up
+        st = ix.line_stats()
+        assert ix.has_minimizer_lines() and ix.minimizer_mphf_kind() == 0 and st["g"] == 0 and st["n_lines"] == 1 << st["t"]
+        assert 0 < st["lines_unusable"] < 0.06 * st["n_lines"] and st["frac_inline"] > 0.85
     if (w, skew) == (15, 16):
         assert ix.n_kmers_in_skew_index() != 0 and ix.n_minimizers() < ix.n_kmers()  # caching.rs:247-248 (see test_boundary)
     rep = ix.validate_self_report()
@@ -393,13 +398,13 @@ def test_reads_crowded_and_very_long(yeast, w, skew):
 
 @pytest.mark.parametrize("prefix,w,skew", [(CF_TINY, 3, M.MZ_NO_SKEW_INDEX), (CF_TINY, 5, 0), (CF_TINY, 1, 2), (CF_TINY, 7, M.MZ_NO_SKEW_INDEX),
                                            (CF_YEAST, 12, 16), (CF_YEAST, 13, 32), (CF_YEAST, 9, 4), (CF_YEAST, 4, M.MZ_NO_SKEW_INDEX),
-                                           (CF_YEAST, 15, 16), (CF_YEAST, 20, 8)])
+                                           (CF_YEAST, 15, 16), (CF_YEAST, 20, 8), (CF_YEAST, 17, 32), (CF_YEAST, 19, 16), (CF_YEAST, 21, 4)])
 def test_gpu_built_index_is_bit_identical_to_host_built(prefix, w, skew, tmp_path):
     """mz_sshash_from_unitig_set_device (minimizer scan, sort, records, EF, entries, skew MPHF on the GPU) must
     produce the very arrays of the host builder: compared through the flat index file, then queried."""
     us = M.UnitigSet.from_cf_prefix(prefix)
     host = M.SSHash.from_unitig_set(us, w, skew)
-    dev = M.SSHash.from_unitig_set_on_device(us, w, skew)   # (15,16) and (20,8) exercise the transparent host fallback
+    dev = M.SSHash.from_unitig_set_on_device(us, w, skew)   # (15,16) and every w > 16 exercise the transparent host fallback
     host.save(tmp_path / "h.mz")
     dev.save(tmp_path / "d.mz")
     a, b = open(tmp_path / "h.mz", "rb").read(), open(tmp_path / "d.mz", "rb").read()

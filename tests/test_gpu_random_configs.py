@@ -136,3 +136,51 @@ def test_bucket_larger_than_a_marker_can_say_without_a_skew_index(reads_lines):
     else:
         assert np.array_equal(got_r["match"] != 0, want["match"] != 0)
     assert cnt[0] >= 3000
+
+
+@pytest.mark.parametrize("k,w,load", [(31, 17, 0), (31, 19, 1000), (31, 21, 2), (27, 18, 40), (63 // 2, 25, 0)])
+def test_hash_addressed_lines_answer_like_the_index_without_them(k, w, load, tmp_path):
+    """2w > 32: the minimizer lines are addressed by a hash of the word and carry an 8-bit fingerprint; lines with a fingerprint clash or more
+    than 16 words are given up and their queries take the MPHF path.  Whatever the load (lines_max_load = 1000 folds everything into
+    a few lines: all given up; 2: sparse), the answers are those of the oracle's dictionary and of the same index without lines,
+    also after a save / load round trip."""
+    rng = np.random.default_rng(k * 100 + w)
+    seed = int(rng.integers(0, 1 << 30))
+    codes, starts = H.random_unitigs(seed, 3000, 250.0, k, max_len=3000)
+    total = int(starts[-1])
+    motif = rng.integers(0, 4, 90, dtype=np.uint8)  # a repeat family: heavy buckets, spilled lines
+    for _ in range(400):
+        p = int(rng.integers(0, total - len(motif)))
+        m = motif.copy()
+        mut = rng.random(len(m)) < 0.08
+        m[mut] = (m[mut] + rng.integers(1, 4, int(mut.sum()))) & 3
+        codes[p:p + len(m)] = m
+    words = H.pack_codes(codes)
+    orc = O.OracleSSHash(words, total, starts, k, w, 8, seed)
+    us = M.UnitigSet.from_packed(words, total, starts, k)
+    q = H.query_mix(words, starts, k, 60000, seed=7)
+    neg1 = q[:20000] ^ (np.uint64(1) << rng.integers(0, 2 * k, 20000).astype(np.uint64))
+    q = np.concatenate([q, neg1])
+    truth, _ = orc.k2u_batch(q, n_threads=8, use_dict=True)
+    plain = M.SSHash.from_unitig_set_opts(us, w, 8, seed, minimizer_lines=-1)
+    assert not plain.has_minimizer_lines()
+    want, _ = plain.k2u_batch(q)
+    ix = M.SSHash.from_unitig_set_opts(us, w, 8, seed, lines_max_load=load)
+    st = ix.line_stats()
+    assert ix.has_minimizer_lines() and st["g"] == 0 and st["n_lines"] == 1 << st["t"]
+    if load == 1000:
+        assert st["lines_unusable"] == st["n_lines"] and st["entries_inline"] == 0
+    elif load == 40:  # ~25 words per line: hardly a line survives, the few that do must still answer
+        assert 0.9 * st["n_lines"] < st["lines_unusable"] < st["n_lines"]
+    else:
+        assert st["lines_unusable"] < 0.1 * st["n_lines"] and st["frac_inline"] > 0.7
+    ix.save(tmp_path / "h.mz")
+    for cand in (ix, M.SSHash.load(tmp_path / "h.mz")):
+        got, _ = cand.k2u_batch(q)
+        assert got.tobytes() == want.tobytes()
+        rep = cand.validate_self_report()
+        assert rep["n_fail"] == 0 and rep["n_kmers"] == cand.n_kmers()
+    if orc.n_duplicate_kmers() == 0:
+        assert want.tobytes() == truth.tobytes()
+    else:
+        assert np.array_equal(want["match"] != 0, truth["match"] != 0)
