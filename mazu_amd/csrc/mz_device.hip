@@ -118,6 +118,9 @@ constexpr int kStopAfter = MZ_STOP_AFTER;
 #ifndef MZ_REC_BATCH
 #define MZ_REC_BATCH 1
 #endif
+#ifndef MZ_POINT_TOUCH
+#define MZ_POINT_TOUCH 0 // experiment (measured: no gain): the point kernel touches the lines of its next tile's first row before S5
+#endif
 #ifndef MZ_ROW_S0
 #define MZ_ROW_S0 1 // wave-scoped point kernel: stage S0 row by row inside SF (see tile_resolve)
 #endif
@@ -440,8 +443,10 @@ struct NoRowS0 { __device__ __forceinline__ void operator()(int) const {} };
 // instructions per query, for kernels that are bound by instruction issue and find most of their lines in the caches)
 // kDefer: an item that needs the exact walk is not walked here: its best[] becomes kBestDefer, tile_result() reports MZ_DEFER and the
 // kernel queues it (defer_push)
-template <class SC, bool kRuns = false, class RowS0 = NoRowS0, bool kFinish = true, int kSfLanes = 8, bool kDefer = false>
-__device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexView &ix, RowS0 s0 = RowS0{}) {
+// PreS5: a callable run right before the sequence-record gathers of S5 go out (experiments with work of the NEXT tile placed there)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <class SC, bool kRuns = false, class RowS0 = NoRowS0, bool kFinish = true, int kSfLanes = 8, bool kDefer = false, class PreS5 = NoHook>
+__device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexView &ix, RowS0 s0 = RowS0{}, PreS5 pre_s5 = PreS5{}) {
     const uint32_t t = SC::tid(), k = ix.k, w = ix.w;
     constexpr bool kHasS0 = !std::is_same<RowS0, NoRowS0>::value;
     static_assert(!kHasS0 || (SC::NT == 64 && !kRuns), "row-wise S0 is for the wave-scoped point kernel");
@@ -972,6 +977,7 @@ __device__ __forceinline__ void tile_resolve(TileLdsT<SC::NT> &S, const IndexVie
         wave_push(S.list_a, &S.cnt_a, S.best[i] != kBestNone, i);
     }
     SC::sync();
+    pre_s5();
     {
         const uint32_t nc = S.cnt_a;
 #ifdef MZ_DEBUG_COUNT
@@ -1328,7 +1334,24 @@ __global__ __launch_bounds__(kBlock, MZ_WAVES_PER_EU) void k2u_wave_kernel(Index
             const uint64_t rc = kmer_rc(fw, k);
             tile_set_query<SC>(S, i, fw, rc, canonical_minimizer(fw, rc, k, w, ix.seed), ix, i < n_valid, ix.front.lines != nullptr);
         };
-#if MZ_ROW_S0
+#if MZ_POINT_TOUCH
+        // experiment: the lines of the NEXT tile's first row are touched (one 4-byte load per lane) right before this tile's record gathers go
+        // out, so that stage SF of the next tile finds them in the L2
+        uint32_t touched = 0;
+        auto touch_next = [&]() {
+            const uint64_t nt = tile + n_waves;
+            if (nt < n_tiles && ix.front.lines != nullptr) {
+                const uint64_t nb = nt * kWT, left = n - nb;
+                const uint64_t fw = fw_words[nb + (t < left ? t : 0u)] & kmask, rc = kmer_rc(fw, k);
+                const Minimizer mn = canonical_minimizer(fw, rc, k, w, ix.seed);
+                const uint64_t line = front_is_hashed(w) ? front_hashed_line(front_hash(mn.word), ix.front.n_lines)
+                                                         : (uint64_t)(((uint32_t)mn.word >> ix.front.g) & (uint32_t)(ix.front.n_lines - 1));
+                touched = *reinterpret_cast<const uint32_t *>(ix.front.lines + line * kFrontSlots);
+            }
+        };
+        tile_resolve<SC, false, decltype(s0_row), true, 8, true, decltype(touch_next)>(S, ix, s0_row, touch_next);
+        asm volatile("" ::"v"(touched));
+#elif MZ_ROW_S0
         tile_resolve<SC, false, decltype(s0_row), true, 8, true>(S, ix, s0_row);
 #else
 #pragma unroll
