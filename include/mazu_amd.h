@@ -129,7 +129,7 @@ typedef struct mz_build_opts {
     uint32_t struct_size;
     int32_t device;                 /* >= 0: heavy steps on that GPU, index left resident there (mz_sshash_from_unitig_set_device); < 0: host builder */
     int32_t n_threads;              /* host threads; <= 0: all */
-    int32_t minimizer_lines;        /* 1: always build the minimizer lines (2w <= 32 only); -1: never; 0: when the table fits the size rule */
+    int32_t minimizer_lines;        /* 1: always build the minimizer lines; -1: never; 0: when the table fits the size rule */
     uint32_t lines_max_load;        /* mean bucket entries per 16-slot line the table may carry (sets g: 3 -> 34 GB, 10 -> 9 GB on a GRCh38-sized set); 0: 3, else 5, else 10 */
     uint64_t direct_bytes_per_key;  /* budget of the direct-address minimizer records, bytes per distinct minimizer; 0: the rule of mz_sshash_minimizer_mphf_kind */
 } mz_build_opts;
