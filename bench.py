@@ -527,7 +527,7 @@ def main():
                          "kernel": {3: "k2u_batch_kernel", 2: "k2u_tile_kernel"}.get(ix.get_query_opts()["point_kernel"], "k2u_wave_kernel"), "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_kmer": B_ALG},
             "timed_region_s": round(elapsed, 4), "collective": collective_info(backend, n_gpus),
-            "build": {"gen_s": round(t_gen, 2), "where": "host" if args.host_build or 2 * args.w > 32 else "gpu",  # (the GPU builder hands minimizers beyond 32 bits to the host builder) "build_and_validate_s": round(t_build, 2),
+            "build": {"gen_s": round(t_gen, 2), "where": "gpu" if ix.built_on_device() else "host", "build_and_validate_s": round(t_build, 2),
                       "rebuilds_for_duplicates": rebuilds, "bits_per_kmer": round(ix.num_bits() / ix.n_kmers(), 2),
                       "lines": {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in ix.line_stats().items()
                                 if kk in ("g", "t", "entries_per_line", "frac_inline", "frac_spilled", "frac_heavy")}},

@@ -196,6 +196,10 @@ typedef struct mz_line_stats {
 int mz_sshash_line_stats(mz_sshash *ix, mz_line_stats *out);
 /* bytes resident in HBM once uploaded */
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix);
+/* 1 when the arrays of this index were constructed by the GPU builder (mz_sshash_from_unitig_set_device / _opts with device >= 0), 0 when
+ * the host builder made them -- asked for, or because the GPU builder handed the configuration over (it is silent about that: the arrays
+ * are bit-identical either way).  No counterpart in the reference (its builder, sshash.rs:86-329, has one form). */
+uint32_t mz_sshash_built_on_device(const mz_sshash *ix);
 
 /* place a replica of the index in the HBM of `device` (kept alongside replicas on other devices) and make it
  * the one host-pointer entry points use; done implicitly on device 0 by the first query.  The *_device

@@ -98,6 +98,7 @@ def _load():
         "mz_sshash_has_minimizer_lines": (u32, [p]),
         "mz_sshash_line_stats": (i, [p, p]),
         "mz_sshash_device_bytes": (u64, [p]),
+        "mz_sshash_built_on_device": (C.c_uint32, [p]),
         "mz_sshash_to_device": (i, [p, i]),
         "mz_sshash_k2u": (i, [p, u64, u32, p]),
         "mz_sshash_k2u_batch": (i, [p, p, u64, p, p]),

@@ -58,6 +58,7 @@ struct mz_sshash {
     std::vector<HostPipe *> idle_pipes;   // guarded by mu
     DeviceIndex *dev = nullptr;           // default replica (first one placed, or the last mz_sshash_to_device target)
     std::vector<DeviceIndex *> replicas;  // one per device the index has been placed on (index replicated per GPU)
+    bool built_on_device = false;         // the GPU builder made the arrays
     std::mutex mu;
 };
 
@@ -230,6 +231,7 @@ static int build_device(const mz_unitig_set *us, uint32_t w, uint64_t skew_param
         DeviceIndex *kept = nullptr; // the GPU builder leaves its arrays in HBM as the replica of `device`: no download, no second upload
         if (gpu_build_supported(us->us, w)) rc = build_on_device(ix->host, us->us, w, skew_param, seed, device, &kept, bo);
         if (rc == MZ_OK && kept) { ix->replicas.push_back(kept); ix->dev = kept; }
+        ix->built_on_device = rc == MZ_OK;
         if (rc == MZ_ENOMEM) { // the device ran out of memory next to what already lives there: the host builder can still do it
             std::fprintf(stderr, "[mazu_amd] GPU index build ran out of device memory (%s); building on the host instead\n", last_error());
             ix->host = SSHashHost();
@@ -277,6 +279,7 @@ uint64_t mz_sshash_num_bits(const mz_sshash *ix) { return ix->host.num_bits(); }
 uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix) { return ix->host.mm.direct ? 1u : 0u; }
 uint32_t mz_sshash_has_minimizer_lines(const mz_sshash *ix) { return ix->host.front.present ? 1u : 0u; }
 uint64_t mz_sshash_device_bytes(const mz_sshash *ix) { return ix->dev ? ix->dev->bytes : 0; } /* per replica */
+uint32_t mz_sshash_built_on_device(const mz_sshash *ix) { return ix && ix->built_on_device ? 1u : 0u; }
 
 int mz_sshash_to_device(mz_sshash *ix, int device) {
     DeviceGuard guard;

@@ -774,23 +774,31 @@ void FrontTable::build(const uint64_t *minrec, uint32_t w, uint64_t n_occ, bool 
     g = t = 0;
 }
 
+// size of the hash-addressed table (2w > 32): a power of two of lines at a mean load of at most 3 entries (else 5, else 10) within the same
+// budget as the direct tables; mz_build_opts decide otherwise
+bool FrontTable::choose_hashed(uint32_t w, uint64_t n_occ, uint64_t n_mm, const BuildOpts &opts, uint32_t &bits) {
+    bits = 0;
+    if (!front_is_hashed(w) || opts.minimizer_lines < 0 || n_mm == 0) return false;
+    const bool forced = opts.minimizer_lines > 0 || opts.lines_max_load >= 1;
+    const uint64_t loads[3] = {3, 5, 10};
+    for (int a = 0; a < 3; ++a) {
+        const uint64_t load = opts.lines_max_load >= 1 ? opts.lines_max_load : opts.minimizer_lines > 0 ? loads[2] : loads[a];
+        bits = 6;
+        while (bits < 32 && n_occ > load * (1ull << bits)) ++bits;
+        if (forced || (kFrontSlots * 8ull << bits) <= front_table_cap(n_occ)) return true;
+    }
+    bits = 0;
+    return false;
+}
+
 void FrontTable::build_hashed(const uint64_t *mm_set, const uint64_t *bucket_of, uint64_t n_mm, uint32_t w, uint64_t n_occ, const uint64_t *psum,
                               const uint64_t *entries, uint64_t skew_param, int n_threads, const BuildOpts &opts) {
     lines.clear();
     present = false;
     g = t = 0;
     n_unusable = 0;
-    if (!front_is_hashed(w) || opts.minimizer_lines < 0 || n_mm == 0) return;
-    // size: a power of two of lines at a mean load of at most 3 entries (else 5, else 10) within the same budget as the direct tables
-    const uint64_t loads[3] = {3, 5, 10};
     uint32_t bits = 0;
-    for (int a = 0; a < 3 && !present; ++a) {
-        const uint64_t load = opts.lines_max_load >= 1 ? opts.lines_max_load : opts.minimizer_lines > 0 ? loads[2] : loads[a];
-        bits = 6;
-        while (bits < 32 && n_occ > load * (1ull << bits)) ++bits;
-        present = opts.minimizer_lines > 0 || opts.lines_max_load >= 1 || (kFrontSlots * 8ull << bits) <= front_table_cap(n_occ);
-        if (opts.minimizer_lines > 0 || opts.lines_max_load >= 1) break;
-    }
+    present = choose_hashed(w, n_occ, n_mm, opts, bits);
     if (!present) return;
     t = bits;
     const uint64_t n_lines = 1ull << bits;

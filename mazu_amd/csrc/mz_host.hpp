@@ -141,6 +141,7 @@ struct FrontTable {
                const BuildOpts &opts);
     // 2w > 32: lines addressed by a hash of the word (front_hash in mz_common.hpp), built from the sorted minimizer set and each
     // word's bucket id; g = 0 and t = log2(lines) then.  unusable: lines given up (fingerprint collision or more than 16 words)
+    static bool choose_hashed(uint32_t w, uint64_t n_occ, uint64_t n_mm, const BuildOpts &opts, uint32_t &bits);
     void build_hashed(const uint64_t *mm_set, const uint64_t *bucket_of, uint64_t n_mm, uint32_t w, uint64_t n_occ, const uint64_t *psum, const uint64_t *entries,
                       uint64_t skew_param, int n_threads, const BuildOpts &opts);
     uint64_t n_unusable = 0;
@@ -165,7 +166,10 @@ struct SSHashHost {
     // until somebody needs them on the host: save(), a replica on another GPU); the scalars and `us` are always here
     bool arrays_on_host = true;
     // sizes of the arrays above in words, from the scalars alone
-    uint64_t n_mm_block_words() const { return mm.direct ? ((((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords) : (uint64_t)mm.blocks.size(); }
+    uint64_t n_mm_block_words() const { // (from the scalars: the arrays may be in HBM only)
+        if (mm.direct) return (((1ull << (2 * w)) >> kMinRecKeysLog2) + 1) * kMinRecWords;
+        return mm.levels.empty() ? 8 : (mm.levels.back().block_off + mm.levels.back().n_blocks) * 8;
+    }
     uint64_t n_bucket_block_words() const { return (((buckets.n - 1) >> kBefShift) + 1) * 8; }
     uint64_t n_bucket_ovf_words() const { return buckets.n_overflow ? buckets.n_overflow * (kBefSpan + 1) : 2; }
 

@@ -220,6 +220,7 @@ class SSHash:  # sshash.rs:39-51
     def minimizer_mphf_kind(self): return lib.mz_sshash_minimizer_mphf_kind(self._h)
     def has_minimizer_lines(self): return bool(lib.mz_sshash_has_minimizer_lines(self._h))
     def device_bytes(self): return lib.mz_sshash_device_bytes(self._h)
+    def built_on_device(self): return bool(lib.mz_sshash_built_on_device(self._h))
 
     def line_stats(self):
         """where the bucket entries are answered from (mz_line_stats), plus the fractions of the entry mass"""

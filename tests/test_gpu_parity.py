@@ -404,7 +404,9 @@ def test_gpu_built_index_is_bit_identical_to_host_built(prefix, w, skew, tmp_pat
     produce the very arrays of the host builder: compared through the flat index file, then queried."""
     us = M.UnitigSet.from_cf_prefix(prefix)
     host = M.SSHash.from_unitig_set(us, w, skew)
-    dev = M.SSHash.from_unitig_set_on_device(us, w, skew)   # (15,16) and every w > 16 exercise the transparent host fallback
+    dev = M.SSHash.from_unitig_set_on_device(us, w, skew)   # (yeast, 15, 16) exercises the transparent host fallback: direct records do not pay for so few minimizers
+    assert not host.built_on_device()
+    assert dev.built_on_device() == ((prefix, w) != (CF_YEAST, 15)), "the GPU builder handed a configuration it should build to the host"
     host.save(tmp_path / "h.mz")
     dev.save(tmp_path / "d.mz")
     a, b = open(tmp_path / "h.mz", "rb").read(), open(tmp_path / "d.mz", "rb").read()
