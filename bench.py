@@ -390,7 +390,7 @@ def bench_reads(args, ix, us, dev, rank, world, D, M, synth, np, torch):
             res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec["hbm_bytes_per_launch"] if rec else None,
                                "traffic_gbs": round(rec["hbm_bytes_per_launch"] / kernel_s / 1e9, 1) if rec else None,
-                               "kernel": "k2u_reads_wave_kernel" if args.w == 15 else "k2u_reads_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4),
+                               "kernel": "k2u_reads_wave_kernel" if args.w in (15, 17, 19, 21) else "k2u_reads_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4),
                                "algorithmic_bytes_per_window": round(b_win, 1), "f_cold": round(f_cold, 4)}
             if rec and rec.get("valu_wave_insts_per_launch"):
                 n_simd, clk = 1024, 2.4e9

@@ -176,7 +176,7 @@ uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix);
  * most 3, else 5, else 10 per line of 16 slots) stays within max(64 MiB, 64 bytes per entry, min(9 GiB, 1 KiB per entry));
  * mz_build_opts.minimizer_lines / lines_max_load decide otherwise.  2w <= 32: lines addressed by the minimizer word itself
  * (direct-address minimizers only); 2w > 32: by a hash of the word, beside the BBHash levels, which stay the exact path for
- * the ~2 % of the lines the builder cannot use (mz_line_stats.lines_unusable) and for reads. */
+ * the ~2 % of the lines the builder cannot use (mz_line_stats.lines_unusable); reads use them at (k, w) = (31, 17 / 19 / 21). */
 uint32_t mz_sshash_has_minimizer_lines(const mz_sshash *ix);
 /* what the minimizer lines hold (this layout's part of print_stats, sshash.rs:360-395): where the bucket entries of the index are answered from.
  * All zero for an index without lines.  Counted on the GPU (the index is placed on device 0 if it is nowhere yet). */

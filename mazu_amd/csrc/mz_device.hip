@@ -1518,6 +1518,52 @@ __device__ __forceinline__ void window_minima_17(const uint32_t *keys, uint32_t 
     out[3] = min(min3u(x[17], x[18], x[19]), mid);
 }
 
+// The same for windows of N keys (N <= 17): thread t takes the windows 4t .. 4t+3, keys 3 .. N-1 of its span are shared.
+template <int N>
+__device__ __forceinline__ void window_minima_n(const uint32_t *keys, uint32_t t, uint32_t (&out)[4]) {
+    static_assert(N >= 4 && N <= 17, "window length");
+    constexpr int kVec = (N + 3 + 3) / 4;
+    uint32_t x[4 * kVec];
+    const uint4 *v = reinterpret_cast<const uint4 *>(keys + 4 * t);
+#pragma unroll
+    for (int a = 0; a < kVec; ++a) { const uint4 q = v[a]; x[4 * a] = q.x; x[4 * a + 1] = q.y; x[4 * a + 2] = q.z; x[4 * a + 3] = q.w; }
+    uint32_t mid = x[3];
+#pragma unroll
+    for (int a = 4; a < N; ++a) mid = min(mid, x[a]);
+    out[0] = min(min3u(x[0], x[1], x[2]), mid);
+    out[1] = min(min3u(x[1], x[2], x[N]), mid);
+    out[2] = min(min3u(x[2], x[N], x[N + 1]), mid);
+    out[3] = min(min3u(x[N], x[N + 1], x[N + 2]), mid);
+}
+// Minimizers of more than 16 bases order their w-mers by a 64-bit hash, which no 32-bit key can carry.  The keys then hold the TOP 20 bits
+// of the hash (hash20 << 12 | position, bit 11 clear): the window minimum over them is the true minimizer unless a second w-mer of the
+// window shows the same 20 bits as the smallest one -- then the lower 44 bits decide, and the window is flagged (bit 11 of the result)
+// so that its caller recomputes the minimizer exactly.  A tie shows when the minimum taken with the positions mirrored (the same
+// smallest hash20 at its OTHER end) lands on a different position.
+constexpr uint32_t kWideHashBits = 20, kWideTieBit = 1u << kTilePosBits;
+template <int N>
+__device__ __forceinline__ void window_minima_tie(const uint32_t *keys, uint32_t t, uint32_t (&out)[4]) {
+    static_assert(N >= 4 && N <= 17, "window length");
+    constexpr int kVec = (N + 3 + 3) / 4;
+    constexpr uint32_t kPosMask = (1u << kTilePosBits) - 1;
+    uint32_t x[4 * kVec];
+    const uint4 *v = reinterpret_cast<const uint4 *>(keys + 4 * t);
+#pragma unroll
+    for (int a = 0; a < kVec; ++a) { const uint4 q = v[a]; x[4 * a] = q.x; x[4 * a + 1] = q.y; x[4 * a + 2] = q.z; x[4 * a + 3] = q.w; }
+    uint32_t mid = x[3], mid_o = x[3] ^ kPosMask;
+#pragma unroll
+    for (int a = 4; a < N; ++a) { mid = min(mid, x[a]); mid_o = min(mid_o, x[a] ^ kPosMask); }
+    auto one = [&](uint32_t a, uint32_t b, uint32_t c) {
+        const uint32_t lo = min(min3u(a, b, c), mid);
+        const uint32_t op = min(min3u(a ^ kPosMask, b ^ kPosMask, c ^ kPosMask), mid_o);
+        return lo | ((op ^ kPosMask) != lo ? kWideTieBit : 0u);
+    };
+    out[0] = one(x[0], x[1], x[2]);
+    out[1] = one(x[1], x[2], x[N]);
+    out[2] = one(x[2], x[N], x[N + 1]);
+    out[3] = one(x[N], x[N + 1], x[N + 2]);
+}
+
 // Every window is looked up through the tile machinery (the loop of bin/kphf/main.rs:314-324); what consecutive windows
 // share -- their minimizer, for ~9 positions -- is resolved once per run (tile_resolve<SC, true>).
 // The `.as_streaming()` shortcut of the reference (index/caching.rs:65-103: try prev.pos+1 on the same
@@ -1659,7 +1705,7 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_kernel(Index
         }
         // S0: one item per base position
         uint64_t out_idx[kQpt];
-        uint32_t state[kQpt]; // 0 = no window here, 1 = window with a non-ACGT byte, 2 = valid k-mer (answer pending)
+        uint32_t state[kQpt]; // 0 = no window here, 1 = window with a non-ACGT byte, 2 = valid k-mer (answer pending), 3 = valid k-mer whose minimizer the 20-bit keys could not decide: straight to the exact walk
         const bool slow = R.slow != 0;
         uint64_t r = R.read0;
 #pragma unroll
@@ -1746,18 +1792,23 @@ __device__ __forceinline__ uint64_t packed_mer(const uint64_t *packed, uint32_t 
 }
 // kPerItemLines: true: every window scans its minimizer line itself (stage SF), as a point query does; false: one lookup per run of windows
 // kGrouped: candidates are verified per group of windows that share a sequence record (tile_finish_grouped) instead of one by one
-template <bool kPerItemLines, bool kGrouped>
+// KW: the compile-time (k, w): (31, 15), or (31, 17 / 19 / 21) with minimizer lines addressed by a hash of the word (per-item form only)
+template <uint32_t KW, bool kPerItemLines, bool kGrouped>
 __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(IndexView ix, const uint8_t *__restrict__ bases, uint64_t n_bases,
                                                                               const uint64_t *__restrict__ read_offsets,
                                                                               const uint64_t *__restrict__ kmer_offsets, uint64_t n_reads,
                                                                               mz_k2upos *__restrict__ out, mz_counts *counts) {
-    fix_kw<kKW3115>(ix);
+    fix_kw<KW>(ix);
     using SC = WaveScope;
     __shared__ TileLdsT<SC::NT> SS[kBlock / 64];
     __shared__ ReadsWaveLds RR[kBlock / 64];
     __shared__ DeferLds DD[kBlock / 64];
-    constexpr uint32_t k = 31, w = 15, n_win = k - w + 1, T = kWaveTile;
-    static_assert(T + n_win - 1 <= kWaveTile + 32 - 12 && 4 * 63 + 19 < kWaveTile + 32, "keys of the tile and its 16-position tail");
+    constexpr uint32_t k = KW >> 8, w = KW & 255u, n_win = k - w + 1, T = kWaveTile;
+    constexpr bool kWide = w > 16; // 64-bit w-mer hashes: 20-bit keys with a tie flag (window_minima_tie)
+    static_assert(k == 31 && w <= k && n_win >= 4 && n_win <= 17, "tail of k - 1 bases, windows of at most 17 keys");
+    static_assert(!kGrouped || KW == kKW3115, "grouped finish: (31, 15) only");
+    static_assert(!kWide || kPerItemLines, "w > 16: through the hash-addressed lines only");
+    static_assert(T + n_win - 1 <= kWaveTile + 32 - 12 && 4 * 63 + n_win + 2 < kWaveTile + 32, "keys of the tile and its tail");
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     TileLdsT<SC::NT> &S = SS[wave];
     ReadsWaveLds &R = RR[wave];
@@ -1862,15 +1913,29 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
             if (lane < kAlignTileWords) R.aligned[kAlignRcAt + lane] = kmer_rc(R.packed()[kAlignTileWords - 1 - lane], 32);
         }
         for (uint32_t j = lane; j < T + n_win - 1; j += 64) { // window keys of both strands (layout: window_minima_17)
-            const uint32_t m = (uint32_t)packed_mer(R.packed(), j, w);
-            R.keys_f[j] = (hash_mmer32(m, ix.seed) << kTilePosBits) | j;
-            R.keys_r[j] = (hash_mmer32((uint32_t)kmer_rc(m, w), ix.seed) << kTilePosBits) | ((1u << kTilePosBits) - 1 - j);
+            if constexpr (kWide) {
+                const uint64_t m = packed_mer(R.packed(), j, w);
+                R.keys_f[j] = ((uint32_t)(hash_mmer64(m, ix.seed) >> (64 - kWideHashBits)) << (kTilePosBits + 1)) | j;
+                R.keys_r[j] = ((uint32_t)(hash_mmer64(kmer_rc(m, w), ix.seed) >> (64 - kWideHashBits)) << (kTilePosBits + 1)) | ((1u << kTilePosBits) - 1 - j);
+            } else {
+                const uint32_t m = (uint32_t)packed_mer(R.packed(), j, w);
+                R.keys_f[j] = (hash_mmer32(m, ix.seed) << kTilePosBits) | j;
+                R.keys_r[j] = (hash_mmer32((uint32_t)kmer_rc(m, w), ix.seed) << kTilePosBits) | ((1u << kTilePosBits) - 1 - j);
+            }
         }
         SC::sync();
         {
             uint32_t wf[4], wr[4]; // window minima in place: every key is read before any is overwritten
-            window_minima_17(R.keys_f, lane, wf);
-            window_minima_17(R.keys_r, lane, wr);
+            if constexpr (kWide) {
+                window_minima_tie<(int)n_win>(R.keys_f, lane, wf);
+                window_minima_tie<(int)n_win>(R.keys_r, lane, wr);
+            } else if constexpr (n_win == 17) {
+                window_minima_17(R.keys_f, lane, wf);
+                window_minima_17(R.keys_r, lane, wr);
+            } else {
+                window_minima_n<(int)n_win>(R.keys_f, lane, wf);
+                window_minima_n<(int)n_win>(R.keys_r, lane, wr);
+            }
             SC::sync();
             *reinterpret_cast<uint4 *>(&R.keys_f[4 * lane]) = uint4{wf[0], wf[1], wf[2], wf[3]};
             *reinterpret_cast<uint4 *>(&R.keys_r[4 * lane]) = uint4{wr[0], wr[1], wr[2], wr[3]};
@@ -1903,14 +1968,15 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
                     state[q] = (inv & ((1ull << k) - 1)) == 0 ? 2u : 1u;
                 }
             }
-            const bool query = state[q] == 2;
-            if (query) {
+            if (state[q] == 2) {
                 fw = packed_mer(R.packed(), i, k);
                 rc = kmer_rc(fw, k);
                 const uint32_t key = fw <= rc ? R.keys_f[i] : R.keys_r[i], low = key & ((1u << kTilePosBits) - 1); // minimum key of the window
                 mn.offset = fw <= rc ? low - i : (k - w) - ((1u << kTilePosBits) - 1 - low - i);
                 mn.word = ((fw <= rc ? fw : rc) >> (2 * mn.offset)) & kmer_mask(w);
+                if (kWide && (key & kWideTieBit)) state[q] = 3; // (lookup() of the deferred walk computes the minimizer from the full hashes)
             }
+            const bool query = state[q] == 2;
             tile_set_query<SC>(S, i, fw, rc, mn, ix, query, kPerItemLines); // (runs are resolved per leader: no per-item line pattern)
             if (state[q] == 1) { // non-ACGT window: reported, never queried
                 mz_k2upos sk = make_none();
@@ -1950,9 +2016,9 @@ __global__ __launch_bounds__(kBlock, MZ_READS_WAVES) void k2u_reads_wave_kernel(
             }
 #pragma unroll
             for (int q = 0; q < kQpt; ++q) {
-                const bool pend = state[q] == 2;
-                const mz_k2upos res = pend ? tile_result<SC>(S, ix, q * 64 + lane) : make_none();
-                const bool defer = pend && res.match == MZ_DEFER;
+                const bool tie = kWide && state[q] == 3, pend = state[q] == 2 || tie;
+                const mz_k2upos res = pend && !tie ? tile_result<SC>(S, ix, q * 64 + lane) : make_none();
+                const bool defer = pend && (tie || res.match == MZ_DEFER);
                 if (pend && !defer) out[out_idx[q]] = res;
                 tally.add(pend && !defer && res.match != MZ_NO_MATCH, pend && !defer && res.match == MZ_NO_MATCH, false);
                 defer_push(D, n_defer, defer, out_idx[q], S.fw[q * 64 + lane], S.qinfo[q * 64 + lane], flush);
@@ -2272,10 +2338,18 @@ int launch_k2u_reads(const DeviceIndex &d, const QueryOpts &opts, const uint8_t 
         // 2.67 rounds --, 24: 31.7, 96: 30.7 G windows/s on s-txome; every wave starts with a search for its first read)
         const dim3 wgrid(tile_grid(d, (n_wave_tiles + kBlock / 64 - 1) / (kBlock / 64), opts.reads_grid > 0 ? (unsigned)opts.reads_grid : 24u));
         const bool per_item = v.front.lines != nullptr && opts.reads_resolve != 2;
-        if (per_item && grouped) MZ_LAUNCH_READS((k2u_reads_wave_kernel<true, true>), wgrid);
-        else if (per_item) MZ_LAUNCH_READS((k2u_reads_wave_kernel<true, false>), wgrid);
-        else if (grouped) MZ_LAUNCH_READS((k2u_reads_wave_kernel<false, true>), wgrid);
-        else MZ_LAUNCH_READS((k2u_reads_wave_kernel<false, false>), wgrid);
+        if (per_item && grouped) MZ_LAUNCH_READS((k2u_reads_wave_kernel<kKW3115, true, true>), wgrid);
+        else if (per_item) MZ_LAUNCH_READS((k2u_reads_wave_kernel<kKW3115, true, false>), wgrid);
+        else if (grouped) MZ_LAUNCH_READS((k2u_reads_wave_kernel<kKW3115, false, true>), wgrid);
+        else MZ_LAUNCH_READS((k2u_reads_wave_kernel<kKW3115, false, false>), wgrid);
+    } else if (v.k == 31 && (v.w == 17 || v.w == 19 || v.w == 21) && d.view.front.lines != nullptr && opts.reads_kernel != 2 && opts.reads_lines >= 0) {
+        // minimizers beyond 32 bits through the hash-addressed lines: the wave-scoped kernel, every window scanning its own line
+        v.front = d.view.front;
+        const uint64_t n_wave_tiles = (n_bases + kWaveTile - 1) / kWaveTile;
+        const dim3 wgrid(tile_grid(d, (n_wave_tiles + kBlock / 64 - 1) / (kBlock / 64), opts.reads_grid > 0 ? (unsigned)opts.reads_grid : 24u));
+        if (v.w == 17) MZ_LAUNCH_READS((k2u_reads_wave_kernel<(31u << 8) | 17u, true, false>), wgrid);
+        else if (v.w == 19) MZ_LAUNCH_READS((k2u_reads_wave_kernel<(31u << 8) | 19u, true, false>), wgrid);
+        else MZ_LAUNCH_READS((k2u_reads_wave_kernel<(31u << 8) | 21u, true, false>), wgrid);
     } else if (v.k == 31 && v.w == 15) {
         MZ_LAUNCH_READS((k2u_reads_kernel<kKW3115>), grid);
     } else {

@@ -146,6 +146,33 @@ def test_s_txome_reads_match_oracle_streaming_walk(bytes_per_key, kind, reads_li
     assert 0.3 < oc[0] / (n_reads * 120) < 0.99  # junction windows and substituted reads miss, the rest hit
 
 
+@pytest.mark.parametrize("w,reads_kernel", [(17, None), (19, None), (21, None), (19, "block"), (20, None)])
+def test_s_txome_reads_with_minimizers_beyond_32_bits_match_oracle(w, reads_kernel):
+    """150-bp reads at w = 17 / 19 / 21: the wave-scoped reads kernel with its 20-bit window keys (a window whose two smallest w-mer hashes
+    agree in those 20 bits is flagged and takes the exact walk: ~200 of the 2.4 M windows here) and every window scanning its hash-addressed
+    minimizer line; w = 20 and reads_kernel = block take the workgroup-staged kernel through the BBHash levels.  Every window must equal
+    the oracle's streaming walk (index/caching.rs:65-103), on sampled reads and on the crafted ones (reverse strand, unitig hops, N, tile edges)."""
+    import torch
+    from mazu_amd import synth
+    us = synth.make_unitig_set("s-txome", device="cuda")
+    ix, rep, _ = synth.build_index_unique(us, w, 32, on_device=True, log=_log)
+    assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and ix.minimizer_mphf_kind() == 0 and ix.has_minimizer_lines() and ix.built_on_device()
+    ix.set_query_opts(reads_kernel=reads_kernel)
+    words, starts = _host_arrays(us)
+    orc = O.OracleSSHash(words, us["total_len"], starts, 31, w, 32, with_dict=False)
+    bases, ro = synth.make_reads(us, 20_000, 150, seed=2000 + w, device="cuda")
+    cb, cro = _crafted_reads(us, np.random.default_rng(w))
+    for b, r in ((bases, ro), (torch.from_numpy(cb).cuda(), torch.from_numpy(cro.astype(np.int64)).cuda())):
+        ko = synth.kmer_offsets(r, 31)
+        out = torch.zeros(int(ko[-1]) * 2, dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(3, dtype=torch.int64, device="cuda")
+        ix.k2u_reads_device(b, r, ko, out, cnt, streaming=True, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want, _, oc = orc.k2u_reads(b.cpu().numpy(), r.cpu().numpy().astype(np.uint64), streaming=True)
+        assert out.cpu().numpy().view(M.K2UPOS_DTYPE).tobytes() == want.tobytes() and cnt.cpu().tolist() == oc.tolist()
+        assert oc[0] > 0.3 * int(ko[-1])
+
+
 def _crafted_reads(us, rng):
     """reads that exercise the verify-and-extend finish of the reads kernel: whole reads on the reverse strand, reads that hop from one
     unitig to a distant one (in both strands), non-ACGT bytes, and lengths that put read ends on every side of the 256-position
