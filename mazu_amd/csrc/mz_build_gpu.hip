@@ -456,15 +456,15 @@ __global__ __launch_bounds__(kB) void wide_entries_kernel(const uint64_t *__rest
         entries[psum[slot[i]] + (j - range[i])] = make_entry(pos, (uint32_t)(pc[j] & 1), flank_of(P.useq, P.total_len, pos, P.w));
     }
 }
-__global__ __launch_bounds__(kB) void hashed_line_of_kernel(const uint64_t *__restrict__ mm, uint64_t n_mm, uint64_t n_lines, uint64_t *__restrict__ line, uint64_t *__restrict__ idx) {
+__global__ __launch_bounds__(kB) void hashed_line_of_kernel(const uint64_t *__restrict__ mm, uint64_t n_mm, uint64_t n_lines, uint32_t *__restrict__ line, uint32_t *__restrict__ idx) {
     uint64_t stride = (uint64_t)gridDim.x * kB;
-    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n_mm; i += stride) {
-        line[i] = front_hashed_line(front_hash(mm[i]), n_lines);
-        idx[i] = i;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n_mm; i += stride) { // (lines and minimizers both number fewer than 2^32)
+        line[i] = (uint32_t)front_hashed_line(front_hash(mm[i]), n_lines);
+        idx[i] = (uint32_t)i;
     }
 }
 // hash-addressed minimizer lines (FrontTable::build_hashed): the lane at the first member of a line packs it; `lines` starts all empty
-__global__ __launch_bounds__(kB) void hashed_lines_kernel(const uint64_t *__restrict__ line, const uint64_t *__restrict__ idx, uint64_t n_mm,
+__global__ __launch_bounds__(kB) void hashed_lines_kernel(const uint32_t *__restrict__ line, const uint32_t *__restrict__ idx, uint64_t n_mm,
                                                           const uint64_t *__restrict__ mm, const uint64_t *__restrict__ slot, const uint64_t *__restrict__ psum,
                                                           const uint64_t *__restrict__ entries, uint64_t skew_param, uint64_t *__restrict__ lines,
                                                           unsigned long long *n_unusable) {
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kB) void hashed_lines_kernel(const uint64_t *__rest
             size[a - i] = psum[b + 1] - psum[b];
             for (uint64_t c = i; c < a; ++c) ok = ok && keyfield[c - i] != keyfield[a - i];
         }
-        uint64_t *dst = lines + line[i] * kFrontSlots;
+        uint64_t *dst = lines + (uint64_t)line[i] * kFrontSlots;
         if (ok) {
             front_pack_line((uint32_t)(j - i), keyfield, first, size, entries, skew_param, out);
 #pragma unroll
@@ -608,6 +608,8 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         BG_HIP(buf.alloc(&d_mm, n_occ));
         BG_HIP(buf.alloc(&d_cnt, n_occ + 1));
         ROCPRIM_RUN(buf, rocprim::run_length_encode(tmp, tmp_bytes, d_keys, n_occ, d_mm, d_cnt, d_nsel));
+        buf.release(d_keys); // (the word of every occurrence: the runs have it from here on)
+        d_keys = nullptr;
     } else {
         const unsigned key_bits = 2 * w + P.key_shift;
         ROCPRIM_RUN(buf, rocprim::radix_sort_keys(tmp, tmp_bytes, d_keys, d_keys2, n_raw, 0, key_bits));
@@ -767,6 +769,9 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         if (wide) {
             BG_HIP(hipMemset(d_packed + n_occ, 0, (n_words - n_occ) * 8)); // (the two pad words)
             hipLaunchKernelGGL(wide_entries_kernel, dim3(grid_of(n_occ)), dim3(kB), 0, 0, d_pc, d_owner, d_range, d_slot, d_psum, n_occ, P, d_packed);
+            BG_HIP(hipDeviceSynchronize());
+            buf.release(d_keys2); buf.release(d_pc2); // (head marks and owners)
+            d_keys2 = d_pc2 = d_owner = nullptr;
         } else {
             hipLaunchKernelGGL(pos_entries_kernel, dim3(grid_of(n_words)), dim3(kB), 0, 0, d_keys, n_occ, P, h.pos.width, n_words, d_packed);
             hipLaunchKernelGGL(record_filters_kernel, dim3(grid_of(n_mm)), dim3(kB), 0, 0, d_minrec, d_mm, n_mm, d_psum, d_packed, skew_param);
@@ -784,7 +789,9 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         if (wide && h.front.present) { // hash-addressed lines (FrontTable::build_hashed): members grouped by line with a stable sort, one lane per line
             h.front.g = 0; h.front.t = hashed_bits;
             const uint64_t n_lines = 1ull << hashed_bits;
-            uint64_t *d_lines = nullptr, *d_line = nullptr, *d_idx = nullptr, *d_line2 = nullptr, *d_idx2 = nullptr;
+            uint64_t *d_lines = nullptr;
+            uint32_t *d_line = nullptr, *d_idx = nullptr, *d_line2 = nullptr, *d_idx2 = nullptr;
+            if (hashed_bits > 32 || n_mm >= (1ull << 32)) { set_error("GPU build unsupported: more than 2^32 minimizers or lines"); return MZ_EINVAL; }
             BG_HIP(buf.alloc(&d_lines, n_lines * kFrontSlots));
             BG_HIP(buf.alloc(&d_line, n_mm)); BG_HIP(buf.alloc(&d_idx, n_mm)); BG_HIP(buf.alloc(&d_line2, n_mm)); BG_HIP(buf.alloc(&d_idx2, n_mm));
             BG_HIP(hipMemset(d_lines, 0xFF, n_lines * kFrontSlots * 8)); // kFrontEmpty
