@@ -15,6 +15,8 @@ bad = 0
 for c in range(n_cfg):
     k = int(rng.choice([31, 31, 31, 29, 27, 25, 21, 17, 30, 24]))
     w = int(rng.integers(max(1, k - 22), min(k, 16) + 1)) if rng.random() < 0.8 else int(rng.integers(1, k + 1))
+    if os.environ.get("STRESS_WIDE"):  # minimizers beyond 32 bits only: BBHash levels + hash-addressed lines, both builders
+        w = int(rng.integers(17, k + 1))
     skew = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64])) if rng.random() < 0.85 else M.MZ_NO_SKEW_INDEX
     seed = int(rng.integers(0, 1 << 30))
     codes, starts = H.random_unitigs(seed, int(rng.integers(50, 1500)), float(rng.choice([40, 150, 600])), k, max_len=3000)
@@ -37,8 +39,14 @@ for c in range(n_cfg):
     q = np.concatenate([q, neg1])
     truth, _ = orc.k2u_batch(q, n_threads=8, use_dict=True)
     dups = orc.n_duplicate_kmers()
+    files = []
     for how in ("host", "gpu"):
         ix = M.SSHash.from_unitig_set(us, w, skew, seed) if how == "host" else M.SSHash.from_unitig_set_on_device(us, w, skew, seed)
+        ix.save("/tmp/stress_%s.mz" % how)
+        files.append(open("/tmp/stress_%s.mz" % how, "rb").read())
+        if how == "gpu" and files[0] != files[1]:
+            bad += 1
+            print(f"cfg {c:3d} k={k} w={w}: index files of the two builders DIFFER (built_on_device={ix.built_on_device()})", flush=True)
         got, _ = ix.k2u_batch(q)
         rep = ix.validate_self_report()
         ok = rep["n_fail"] == 0 and rep["n_kmers"] == ix.n_kmers()

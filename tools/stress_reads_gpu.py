@@ -18,6 +18,8 @@ letters = np.frombuffer(b"ACGT", dtype=np.uint8)
 bad = 0
 for c in range(n_cfg):
     k, w = (31, 15) if rng.random() < 0.7 else (int(rng.choice([31, 27, 21])), int(rng.choice([9, 11, 13])))
+    if os.environ.get("STRESS_WIDE"):  # (31, 17 / 19 / 21): the wave-scoped kernel through hash-addressed lines; other w > 16: the workgroup-staged one
+        k, w = 31, int(rng.choice([17, 19, 21, 21, 19, 18, 25]))
     skew = int(rng.choice([4, 16, 32]))
     seed = int(rng.integers(0, 1 << 30))
     # small key universes get direct records + lines; (31, 15) sets are forced onto them half of the time
