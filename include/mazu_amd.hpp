@@ -108,6 +108,19 @@ public:
         check(mz_sshash_from_unitig_set(unitigs.h_, (uint32_t)w, skew_param == SIZE_MAX ? MZ_NO_SKEW_INDEX : skew_param, seed, 0, &h));
         return SSHash(h);
     }
+    // the same construction with this library's layout choices (mz_build_opts: where to build, minimizer lines, record budget); none changes a result
+    static SSHash from_unitig_set_opts(const UnitigSet &unitigs, size_t w, size_t skew_param, uint64_t seed, mz_build_opts opts) {
+        mz_sshash *h = nullptr;
+        opts.struct_size = (uint32_t)sizeof(mz_build_opts);
+        check(mz_sshash_from_unitig_set_opts(unitigs.h_, (uint32_t)w, skew_param == SIZE_MAX ? MZ_NO_SKEW_INDEX : skew_param, seed, &opts, &h));
+        return SSHash(h);
+    }
+    bool built_on_device() const { return mz_sshash_built_on_device(h_) != 0; }
+    bool has_minimizer_lines() const { return mz_sshash_has_minimizer_lines(h_) != 0; }
+    void set_query_opts(mz_query_opts opts) { // kernel choices of this handle's query entry points
+        opts.struct_size = (uint32_t)sizeof(mz_query_opts);
+        check(mz_sshash_set_query_opts(h_, &opts));
+    }
     static SSHash from_unitig_set_no_skew_index(const UnitigSet &unitigs, size_t w, uint64_t seed = 0) { // :397-403
         return from_unitig_set(unitigs, w, SIZE_MAX, seed);
     }

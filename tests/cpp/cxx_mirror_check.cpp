@@ -48,6 +48,18 @@ int main(int argc, char **argv) {
     REQUIRE(all_skew.n_kmers_in_skew_index() == all_skew.n_kmers());
     StreamingK2U st = all_skew.as_streaming();
     REQUIRE(st.k2u_streaming(CanonicalKmer("CACACAC")).has_value());
+    {   // construction with layout choices: built by the GPU builder, minimizer lines forced, the workgroup-scoped point kernel; same answers
+        mz_build_opts bo{};
+        bo.device = 0;
+        bo.minimizer_lines = 1;
+        SSHash opt = SSHash::from_unitig_set_opts(unitigs, 3, 0, 0, bo);
+        REQUIRE(opt.built_on_device() && opt.has_minimizer_lines());
+        mz_query_opts qo{};
+        qo.point_kernel = 2;
+        opt.set_query_opts(qo);
+        REQUIRE(opt.k2u(CanonicalKmer("CACACAC")).has_value() && !opt.k2u(CanonicalKmer("AAAAAAA")).has_value());
+        opt.validate_self();
+    }
     std::puts("gpu-ok");
     return 0;
 }
