@@ -140,13 +140,21 @@ def host_check():
 
 
 @pytest.mark.parametrize("prefix,w,skew", [(CF_TINY, 3, "none"), (CF_TINY, 5, "0"), (CF_TINY, 7, "none"), (CF_TINY, 1, "2"),
-                                           (CF_YEAST, 15, "none"), (CF_YEAST, 15, "32"), (CF_YEAST, 15, "16"), (CF_YEAST, 9, "4"), (CF_YEAST, 4, "none")])
+                                           (CF_YEAST, 15, "none"), (CF_YEAST, 15, "32"), (CF_YEAST, 15, "16"), (CF_YEAST, 9, "4"), (CF_YEAST, 4, "none"),
+                                           (CF_YEAST, 12, "16"), (CF_YEAST, 17, "32"), (CF_YEAST, 19, "16"), (CF_YEAST, 21, "none"), (CF_YEAST, 31, "4")])
 def test_builder_layout_self_consistent_on_host(host_check, prefix, w, skew):
     """TEST-ONLY host evaluation of the shared lookup chain over the arrays the builder produced
-    (the product exports no such entry point): every k-mer, both orientations."""
+    (the product exports no such entry point): every k-mer, both orientations.  Where the builder made minimizer lines -- addressed by
+    the minimizer word, or by a hash of it at w > 16 -- a plain restatement of how the kernels read a line must give the chain's answer
+    for every k-mer, its reverse complement and a one-base neighbour, and most answers must come from the line itself."""
+    import json
     r = subprocess.run([host_check, "validate", prefix, str(w), skew, "0"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert '"n_fail": 0' in r.stdout
+    rep = json.loads(r.stdout)
+    assert rep["n_fail"] == 0 and rep["line_fail"] == 0
+    if w > 16 or (prefix, w) == (CF_YEAST, 12):
+        assert rep["lines"] == 1 and rep["answered_from_line"] > 2.5 * rep["n_kmers"], rep  # of 3 queries per k-mer
+        assert (rep["lines_unusable"] > 0) == (w > 16)
 
 
 def test_builder_layout_matches_oracle_on_mixed_queries(host_check, tmp_path):
