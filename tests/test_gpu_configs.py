@@ -320,20 +320,29 @@ def test_s_human_full_size_properties():
     _full_size_properties("s-human", 4_000_000)
 
 
-def test_s_human_reads_match_oracle_streaming_walk():
+@pytest.mark.parametrize("w", [15, 19])
+def test_s_human_reads_match_oracle_streaming_walk(w):
     """100 000 reads (12 M windows) on the full-size GRCh38-shaped set against the ORACLE's StreamingK2U walk (its own index,
-    built here from the same unitig set), through both verify forms: no self-comparison at the headline size"""
+    built here from the same unitig set), through both verify forms: no self-comparison at the headline size.  w = 19: the index the
+    GPU builder makes for minimizers beyond 32 bits (BBHash levels + hash-addressed lines), the reads kernel with 20-bit window keys (about
+    a thousand of the 12 M windows are undecided by them and take the exact walk), and 2.4 M point queries against the oracle as well."""
     import torch
     from mazu_amd import synth
     us = synth.make_unitig_set("s-human", device="cuda")
-    ix, rep, _ = synth.build_index_unique(us, 15, 32, on_device=True, log=_log)
-    assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0
+    ix, rep, _ = synth.build_index_unique(us, w, 32, on_device=True, log=_log)
+    assert rep["n_fail"] == 0 and rep["n_duplicate"] == 0 and ix.built_on_device() and ix.has_minimizer_lines()
     n_reads, read_len = 100_000, 150
     bases, ro = synth.make_reads(us, n_reads, read_len, seed=2000, device="cuda")
     ko = synth.kmer_offsets(ro, 31)
     n_win = int(ko[-1])
     got = {}
-    for verify in ("each", "group"):
+    point = None
+    if w > 16:
+        qq = torch.cat([synth.make_query_mix(ix, us, 2_000_000, seed=11, device="cuda"), synth.make_query_mix(ix, us, 400_000, seed=12, device="cuda", neg_kind="sub1")])
+        out_p, cnt_p = _k2u_device(ix, qq)
+        point = (qq.cpu().numpy().view(np.uint64), out_p.cpu().numpy().view(M.K2UPOS_DTYPE), cnt_p)
+        del qq, out_p
+    for verify in (("each", "group") if w == 15 else ("each",)):
         ix.set_query_opts(reads_verify=verify)
         out = torch.zeros(n_win * 2, dtype=torch.int64, device="cuda")
         cnt = torch.zeros(3, dtype=torch.int64, device="cuda")
@@ -348,12 +357,16 @@ def test_s_human_reads_match_oracle_streaming_walk():
     del us
     os.environ["OMP_NUM_THREADS"] = str(M.lib.mz_host_threads())
     _log("building the oracle's index of s-human on the host ...")
-    orc = O.OracleSSHash(words, total, starts, 31, 15, 32, with_dict=False)
+    orc = O.OracleSSHash(words, total, starts, 31, w, 32, with_dict=False)
     _log("oracle streaming walk over 12 M windows ...")
     want, _, oc = orc.k2u_reads(bases_h, ro_h, streaming=True)
     for verify, (g, c) in got.items():
         assert g.tobytes() == want.tobytes() and c == oc.tolist(), verify
     assert 0.3 < oc[0] / n_win < 0.99
+    if point is not None:
+        q_h, got_p, (n_hit, n_miss, _) = point
+        want_p, o_hit = orc.k2u_batch(q_h, n_threads=M.lib.mz_host_threads())
+        assert got_p.tobytes() == want_p.tobytes() and (n_hit, n_miss) == (o_hit, len(q_h) - o_hit)
 
 
 def test_s_pan_full_size_properties():
