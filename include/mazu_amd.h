@@ -176,7 +176,8 @@ uint32_t mz_sshash_minimizer_mphf_kind(const mz_sshash *ix);
  * most 3, else 5, else 10 per line of 16 slots) stays within max(64 MiB, 64 bytes per entry, min(9 GiB, 1 KiB per entry));
  * mz_build_opts.minimizer_lines / lines_max_load decide otherwise.  2w <= 32: lines addressed by the minimizer word itself
  * (direct-address minimizers only); 2w > 32: by a hash of the word, beside the BBHash levels, which stay the exact path for
- * the ~2 % of the lines the builder cannot use (mz_line_stats.lines_unusable); reads use them at (k, w) = (31, 17 / 19 / 21). */
+ * the ~0.5 % of the words that share a 9-bit fingerprint with another word of their line (mz_line_stats.buckets_walk); reads use
+ * them at (k, w) = (31, 17 / 19 / 21). */
 uint32_t mz_sshash_has_minimizer_lines(const mz_sshash *ix);
 /* what the minimizer lines hold (this layout's part of print_stats, sshash.rs:360-395): where the bucket entries of the index are answered from.
  * All zero for an index without lines.  Counted on the GPU (the index is placed on device 0 if it is nowhere yet). */
@@ -190,8 +191,9 @@ typedef struct mz_line_stats {
     uint64_t buckets_heavy;   /* buckets beyond skew_param: answered by the skew index */
     uint64_t entries_heavy;
     uint64_t slots_empty;
-    uint64_t lines_unusable;  /* 2w > 32 only (lines addressed by a hash of the word, g = 0, t = log2 n_lines): lines given up because two of */
-    uint64_t entries_unusable; /* their words share a fingerprint or more than 16 words fell into them; their queries take the MPHF path */
+    uint64_t lines_unusable;  /* 2w > 32 only (lines addressed by a hash of the word, g = 0, t = log2 n_lines): lines given up because more than */
+    uint64_t entries_unusable; /* 16 words fell into them; entries whose queries take the exact walk through the MPHF (given-up lines and buckets_walk) */
+    uint64_t buckets_walk;    /* markers without a size: words that share a fingerprint in their hash-addressed line, or a bucket of 65535 entries and more */
 } mz_line_stats;
 int mz_sshash_line_stats(mz_sshash *ix, mz_line_stats *out);
 /* bytes resident in HBM once uploaded */

@@ -40,7 +40,7 @@ class QueryOpts(C.Structure):  # mz_query_opts
 class LineStats(C.Structure):  # mz_line_stats
     _fields_ = [("n_lines", C.c_uint64), ("g", C.c_uint32), ("t", C.c_uint32), ("entries_total", C.c_uint64), ("entries_inline", C.c_uint64),
                 ("buckets_spilled", C.c_uint64), ("entries_spilled", C.c_uint64), ("buckets_heavy", C.c_uint64), ("entries_heavy", C.c_uint64),
-                ("slots_empty", C.c_uint64), ("lines_unusable", C.c_uint64), ("entries_unusable", C.c_uint64)]
+                ("slots_empty", C.c_uint64), ("lines_unusable", C.c_uint64), ("entries_unusable", C.c_uint64), ("buckets_walk", C.c_uint64)]
 
 
 class ValidateReport(C.Structure):

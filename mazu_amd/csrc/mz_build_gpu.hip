@@ -476,17 +476,19 @@ __global__ __launch_bounds__(kB) void hashed_lines_kernel(const uint32_t *__rest
         uint64_t out[kFrontSlots];
         uint32_t keyfield[kFrontSlots];
         uint64_t first[kFrontSlots], size[kFrontSlots];
-        bool ok = j - i <= kFrontSlots;
+        const bool ok = j - i <= kFrontSlots;
         for (uint64_t a = i; a < j && ok; ++a) {
             const uint64_t mi = idx[a], b = slot[mi];
             keyfield[a - i] = front_hashed_keyfield(front_hash(mm[mi]));
             first[a - i] = psum[b];
             size[a - i] = psum[b + 1] - psum[b];
-            for (uint64_t c = i; c < a; ++c) ok = ok && keyfield[c - i] != keyfield[a - i];
         }
         uint64_t *dst = lines + (uint64_t)line[i] * kFrontSlots;
         if (ok) {
-            front_pack_line((uint32_t)(j - i), keyfield, first, size, entries, skew_param, out);
+            uint32_t nw = 0;
+            const uint32_t m = front_merge_clashes((uint32_t)(j - i), keyfield, first, size, &nw);
+            if (nw) atomicAdd(n_unusable + 1, (unsigned long long)nw);
+            front_pack_line(m, keyfield, first, size, entries, skew_param, out);
 #pragma unroll
             for (uint32_t q = 0; q < kFrontSlots; ++q) dst[q] = out[q];
         } else {
@@ -783,7 +785,7 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
         }
         // minimizer lines from the finished records, bucket starts and entries
         h.front.lines.clear();
-        h.front.n_unusable = 0;
+        h.front.n_unusable = h.front.n_walk = 0;
         uint32_t hashed_bits = 0;
         h.front.present = wide ? FrontTable::choose_hashed(w, n_occ, n_mm, opts, hashed_bits) : FrontTable::choose(w, n_occ, true, opts, h.front.g, h.front.t);
         if (wide && h.front.present) { // hash-addressed lines (FrontTable::build_hashed): members grouped by line with a stable sort, one lane per line
@@ -797,12 +799,13 @@ int build_on_device(SSHashHost &h, const UnitigSet &unitigs, uint32_t w, uint64_
             BG_HIP(hipMemset(d_lines, 0xFF, n_lines * kFrontSlots * 8)); // kFrontEmpty
             hipLaunchKernelGGL(hashed_line_of_kernel, dim3(grid_of(n_mm)), dim3(kB), 0, 0, d_mm, n_mm, n_lines, d_line, d_idx);
             ROCPRIM_RUN(buf, rocprim::radix_sort_pairs(tmp, tmp_bytes, d_line, d_line2, d_idx, d_idx2, n_mm, 0, std::max(hashed_bits, 1u)));
-            BG_HIP(hipMemset(d_counter, 0, 8));
+            BG_HIP(hipMemset(d_counter, 0, 16));
             hipLaunchKernelGGL(hashed_lines_kernel, dim3(grid_of(n_mm)), dim3(kB), 0, 0, d_line2, d_idx2, n_mm, d_mm, d_slot, d_psum, d_packed, skew_param, d_lines, d_counter);
             BG_HIP(hipGetLastError());
-            unsigned long long n_un = 0;
-            BG_HIP(hipMemcpy(&n_un, d_counter, 8, hipMemcpyDeviceToHost));
-            h.front.n_unusable = n_un;
+            unsigned long long n_un[2] = {0, 0}; // lines given up, walk markers
+            BG_HIP(hipMemcpy(n_un, d_counter, 16, hipMemcpyDeviceToHost));
+            h.front.n_unusable = n_un[0];
+            h.front.n_walk = n_un[1];
             buf.release(d_line); buf.release(d_idx); buf.release(d_line2); buf.release(d_idx2);
             if (!resident) {
                 if (int rc = download(h.front.lines, d_lines, n_lines * kFrontSlots)) return rc;

@@ -713,10 +713,10 @@ int mz_sshash_line_stats(mz_sshash *ix, mz_line_stats *out) {
     if (rc != MZ_OK) return rc;
     HIPC(hipSetDevice(ix->dev->device));
     uint64_t *d = nullptr;
-    HIPC(hipMalloc((void **)&d, 7 * 8));
-    uint64_t h[7] = {0, 0, 0, 0, 0, 0, 0};
-    hipError_t e = hipMemset(d, 0, 7 * 8);
-    if (e == hipSuccess) { rc = launch_line_stats(*ix->dev, d, nullptr); e = hipMemcpy(h, d, 7 * 8, hipMemcpyDeviceToHost); }
+    HIPC(hipMalloc((void **)&d, 8 * 8));
+    uint64_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipError_t e = hipMemset(d, 0, 8 * 8);
+    if (e == hipSuccess) { rc = launch_line_stats(*ix->dev, d, nullptr); e = hipMemcpy(h, d, 8 * 8, hipMemcpyDeviceToHost); }
     (void)hipFree(d);
     if (rc != MZ_OK) return rc;
     if (e != hipSuccess) { set_error("HIP error %d (%s) in mz_sshash_line_stats", (int)e, hipGetErrorString(e)); return MZ_EHIP; }
@@ -726,6 +726,7 @@ int mz_sshash_line_stats(mz_sshash *ix, mz_line_stats *out) {
     out->entries_inline = h[0]; out->buckets_spilled = h[1]; out->entries_spilled = h[2]; out->buckets_heavy = h[3];
     out->entries_heavy = ix->host.pos.n - h[0] - h[2]; // (a heavy marker's own count saturates at 65535: what is neither inline nor spilled is heavy)
     out->slots_empty = h[5];
+    out->buckets_walk = h[7];
     if (front_is_hashed(ix->host.w)) { // what is neither inline nor behind a marker sits in lines the builder gave up (heavy counts saturate per marker: lower bound)
         out->lines_unusable = h[6];
         out->entries_heavy = h[4];

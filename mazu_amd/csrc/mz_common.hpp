@@ -496,17 +496,38 @@ MZ_HD uint32_t front_line_members(const uint64_t *minrec, uint32_t g, uint64_t g
     return (uint32_t)((wv >> bi) & ((1ull << (1u << g)) - 1)); // 2^g <= 16 keys never straddle a bitmap word
 }
 // Minimizer lines for w-mers of more than 32 bits (2w > 32).  The words cannot address the table, so a HASH of the word does:
-// line = low bits of front_hash(word), and the slot's key field carries 8 more bits of the hash.  The fingerprint is not the key,
-// so the builder keeps the table exact another way: a line in which two member words share a fingerprint, or that more than 16
-// member words hash to, is not used at all -- its first slot is kFrontUnusable and a query that meets it takes the exact walk
-// through the MPHF (about 2 % of the lines at a mean of 2 entries per line).  In every other line each member word owns slots
-// under a fingerprint of its own, so "no slot with my fingerprint" means "not a minimizer of the set", and a foreign word that
-// happens to share a member's fingerprint is caught like every false candidate: by the flanks, then by the sequence.
+// line = low bits of front_hash(word), and the slot's key field carries 9 more bits of the hash as a fingerprint.  The fingerprint is
+// not the key, so the builder keeps the table exact another way: member words of a line that share a fingerprint get ONE slot between
+// them, a marker that says "take the exact walk through the MPHF" (a spill marker whose size field is saturated, kFrontWalkSize), and a
+// line that more than 16 member words hash to is not used at all (its first slot is kFrontUnusable; its queries walk too).  Every other
+// member word owns slots under a fingerprint of its own, so "no slot with my fingerprint" means "not a minimizer of the set", and a
+// foreign word that happens to share a member's fingerprint is caught like every false candidate: by the flanks, then by the sequence.
+// At a mean of 2.4 member words per line 0.5 % of the words sit behind a walk marker.
 constexpr uint64_t kFrontHashSeed = 0x6d617a755f66726full;
 MZ_HD uint64_t front_hash(uint64_t word) { const uint64_t h = mum(word ^ kFrontHashSeed, kP3); return h ^ (h >> 29); }
 MZ_HD bool front_is_hashed(uint32_t w) { return 2 * w > 32; }
 MZ_HD uint64_t front_hashed_line(uint64_t h, uint64_t n_lines) { return h & (n_lines - 1); }
-MZ_HD uint32_t front_hashed_keyfield(uint64_t h) { return (uint32_t)(h >> 56); }
+MZ_HD uint32_t front_hashed_keyfield(uint64_t h) { // 9 bits; 0x100 (the pattern of an idle query, the key of kFrontUnusable) and 0x1FF are left out
+    const uint32_t f = (uint32_t)(h >> 55);
+    return f == 0x100u || f == 0x1FFu ? f ^ 0x80u : f;
+}
+constexpr uint64_t kFrontWalkSize = ~0ull; // bucket size of a member that only gets a walk marker (front_merge_clashes)
+// member words of one line that share a fingerprint are merged into one member of size kFrontWalkSize (member order kept); returns the new count
+MZ_HD uint32_t front_merge_clashes(uint32_t m, uint32_t *keyfield, uint64_t *first, uint64_t *size, uint32_t *n_walk) {
+    uint32_t o = 0;
+    for (uint32_t a = 0; a < m; ++a) {
+        bool clash = false;
+        for (uint32_t c = 0; c < o && !clash; ++c)
+            if (keyfield[c] == keyfield[a]) {
+                if (size[c] != kFrontWalkSize) ++*n_walk;
+                size[c] = kFrontWalkSize;
+                first[c] = 0;
+                clash = true;
+            }
+        if (!clash) { keyfield[o] = keyfield[a]; first[o] = first[a]; size[o] = size[a]; ++o; }
+    }
+    return o;
+}
 constexpr uint64_t kFrontUnusable = ((uint64_t)0x100u << kFrontKeyShift) | kFrontSpill; // key field 0x100: no query shows it
 // Packs the m <= 16 member keys of one line (key field, first entry and size of each bucket) into its 16 slots.  Light buckets
 // are taken inline in order of increasing size (ties: member order) while every bucket left out still keeps one slot for
@@ -536,7 +557,7 @@ MZ_HD void front_pack_line(uint32_t m, const uint32_t *keyfield, const uint64_t 
                 out[o++] = front_entry_slot(ent >> 17, cls, cls ? flank_revcomp(fl) : fl, keyfield[a]);
             }
         } else {
-            out[o++] = front_marker_slot(size[a] > skew_param ? kFrontHeavy : kFrontSpill, keyfield[a], first[a], size[a]);
+            out[o++] = front_marker_slot(size[a] != kFrontWalkSize && size[a] > skew_param ? kFrontHeavy : kFrontSpill, keyfield[a], first[a], size[a]);
         }
     }
     for (; o < kFrontSlots; ++o) out[o] = kFrontEmpty;

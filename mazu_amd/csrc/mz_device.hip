@@ -2133,17 +2133,20 @@ __global__ __launch_bounds__(kBlock, 4) void validate_self_kernel(IndexView ix, 
 
 // what the minimizer lines hold, by slot kind (the layout's own print_stats, cf. sshash.rs:360-395): out[0] entries inline,
 // [1] buckets behind a spill marker, [2] their entries, [3] heavy buckets, [4] their entries (a marker's count saturates at
-// 65535), [5] empty slots, [6] hash-addressed lines the builder gave up (kFrontUnusable)
-constexpr int kLineStatWords = 7;
+// 65535), [5] empty slots, [6] hash-addressed lines the builder gave up (kFrontUnusable), [7] markers without a size (exact walk: a bucket
+// too large for the field, or member words that share a fingerprint in a hash-addressed line)
+constexpr int kLineStatWords = 8;
 __global__ __launch_bounds__(kBlock) void line_stats_kernel(const uint64_t *__restrict__ lines, uint64_t n_slots, unsigned long long *out) {
-    unsigned long long c[kLineStatWords] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c[kLineStatWords] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_slots; i += stride) {
         const uint64_t e = lines[i];
         const uint32_t kind = (uint32_t)e & 3u, cnt = (uint32_t)(e >> kFrontFlankShift) & 0xFFFFu;
         c[0] += kind == kFrontEntry;
-        c[1] += kind == kFrontSpill && e != kFrontUnusable; c[2] += kind == kFrontSpill ? cnt : 0u;
+        const bool sized = cnt != 0xFFFFu;
+        c[1] += kind == kFrontSpill && e != kFrontUnusable && sized; c[2] += kind == kFrontSpill && sized ? cnt : 0u;
         c[6] += e == kFrontUnusable;
+        c[7] += kind == kFrontSpill && !sized;
         c[3] += kind == kFrontHeavy; c[4] += kind == kFrontHeavy ? cnt : 0u;
         c[5] += kind == kFrontEmptyKind;
     }

@@ -45,7 +45,7 @@ int launch_k2u_reads(const DeviceIndex &d, const QueryOpts &opts, const uint8_t 
 // d_report: 5 x u64 {n_kmers, n_fail, n_duplicate, first_fail_pos, n_listed}; caller initialises {0,0,0,~0,0}.
 // d_dup_list (may be null): receives up to dup_cap global positions of k-mers whose canonical word occurs earlier too
 int launch_validate_self(const DeviceIndex &d, uint64_t *d_report, uint64_t *d_dup_list, uint64_t dup_cap, hipStream_t stream);
-// d_out: 7 x u64, zeroed by the caller (see line_stats_kernel)
+// d_out: 8 x u64, zeroed by the caller (see line_stats_kernel)
 int launch_line_stats(const DeviceIndex &d, uint64_t *d_out, hipStream_t stream);
 int launch_extract_kmers(const DeviceIndex &d, const uint64_t *d_positions, const uint8_t *d_flip, uint64_t n,
                          uint64_t *d_fw, hipStream_t stream);

@@ -796,7 +796,7 @@ void FrontTable::build_hashed(const uint64_t *mm_set, const uint64_t *bucket_of,
     lines.clear();
     present = false;
     g = t = 0;
-    n_unusable = 0;
+    n_unusable = n_walk = 0;
     uint32_t bits = 0;
     present = choose_hashed(w, n_occ, n_mm, opts, bits);
     if (!present) return;
@@ -820,8 +820,8 @@ void FrontTable::build_hashed(const uint64_t *mm_set, const uint64_t *bucket_of,
         while (c > 0 && c < n_mm && by[c].word == by[c - 1].word) ++c; // a shard starts at the first word of a line
         bounds[sh] = c;
     }
-    std::vector<uint64_t> bad((size_t)std::max(n_threads, 1), 0);
-    uint64_t *L = lines.data(), *BAD = bad.data();
+    std::vector<uint64_t> bad((size_t)std::max(n_threads, 1), 0), walk((size_t)std::max(n_threads, 1), 0);
+    uint64_t *L = lines.data(), *BAD = bad.data(), *WALK = walk.data();
     const Occ *BY = by.data();
     const uint64_t *BO = bounds.data();
     parallel_tasks(n_threads, n_shards, [=](int th, uint64_t sh) {
@@ -833,20 +833,24 @@ void FrontTable::build_hashed(const uint64_t *mm_set, const uint64_t *bucket_of,
             uint64_t *out = L + BY[i].word * kFrontSlots;
             uint32_t keyfield[kFrontSlots];
             uint64_t first[kFrontSlots], size[kFrontSlots];
-            bool ok = j - i <= kFrontSlots;
+            const bool ok = j - i <= kFrontSlots;
             for (uint64_t a = i; a < j && ok; ++a) {
                 const uint64_t mi = BY[a].pos, b = bucket_of[mi];
                 keyfield[a - i] = front_hashed_keyfield(front_hash(mm_set[mi]));
                 first[a - i] = psum[b];
                 size[a - i] = psum[b + 1] - psum[b];
-                for (uint64_t c = i; c < a; ++c) ok = ok && keyfield[c - i] != keyfield[a - i]; // two member words under one fingerprint
             }
-            if (ok) front_pack_line((uint32_t)(j - i), keyfield, first, size, entries, skew_param, out);
-            else { out[0] = kFrontUnusable; ++BAD[th]; }
+            if (ok) {
+                uint32_t nw = 0;
+                const uint32_t m = front_merge_clashes((uint32_t)(j - i), keyfield, first, size, &nw); // member words under one fingerprint: one walk marker between them
+                WALK[th] += nw;
+                front_pack_line(m, keyfield, first, size, entries, skew_param, out);
+            } else { out[0] = kFrontUnusable; ++BAD[th]; }
             i = j;
         }
     });
     for (uint64_t x : bad) n_unusable += x;
+    for (uint64_t x : walk) n_walk += x;
 }
 
 int SSHashHost::build(const UnitigSet &unitigs, uint32_t w_, uint64_t skew_param_, uint64_t seed_, int n_threads, const BuildOpts &opts_) {

@@ -140,11 +140,11 @@ struct FrontTable {
     void build(const uint64_t *minrec, uint32_t w, uint64_t n_occ, bool direct, const uint64_t *psum, const uint64_t *entries, uint64_t skew_param, int n_threads,
                const BuildOpts &opts);
     // 2w > 32: lines addressed by a hash of the word (front_hash in mz_common.hpp), built from the sorted minimizer set and each
-    // word's bucket id; g = 0 and t = log2(lines) then.  unusable: lines given up (fingerprint collision or more than 16 words)
+    // word's bucket id; g = 0 and t = log2(lines) then
     static bool choose_hashed(uint32_t w, uint64_t n_occ, uint64_t n_mm, const BuildOpts &opts, uint32_t &bits);
     void build_hashed(const uint64_t *mm_set, const uint64_t *bucket_of, uint64_t n_mm, uint32_t w, uint64_t n_occ, const uint64_t *psum, const uint64_t *entries,
                       uint64_t skew_param, int n_threads, const BuildOpts &opts);
-    uint64_t n_unusable = 0;
+    uint64_t n_unusable = 0, n_walk = 0; // lines given up (more than 16 words); walk markers (words sharing a fingerprint in their line)
     FrontView view() const { return present ? FrontView{lines.data(), (uint64_t)lines.size() / kFrontSlots, g, t} : FrontView{nullptr, 0, 0, 0}; }
     uint64_t n_words(uint32_t w) const { return !present ? 0 : front_is_hashed(w) ? (uint64_t)kFrontSlots << t : (1ull << (2 * w - g - t)) * kFrontSlots; }
 };

@@ -94,11 +94,11 @@ int main(int argc, char **argv) {
         fails += line_fails;
         std::printf("{\"n_kmers\": %llu, \"n_fail\": %llu, \"n_minimizers\": %llu, \"n_occs\": %llu, \"n_skew\": %llu, \"mphf_levels\": %zu, "
                     "\"ef_overflow_blocks\": %llu, \"direct\": %u, \"minrec_overflow\": %llu, \"num_bits\": %llu, \"build_s\": %.3f, \"lines\": %u, \"line_fail\": %llu, "
-                    "\"answered_from_line\": %llu, \"lines_unusable\": %llu}\n",
+                    "\"answered_from_line\": %llu, \"lines_unusable\": %llu, \"walk_markers\": %llu}\n",
                     (unsigned long long)n, (unsigned long long)fails, (unsigned long long)h.n_minimizers, (unsigned long long)h.pos.n,
                     (unsigned long long)(h.has_skew ? h.skew.n_keys : 0), h.mm.levels.size(), (unsigned long long)h.buckets.n_overflow, h.mm.direct, (unsigned long long)h.n_minrec_overflow,
                     (unsigned long long)h.num_bits(), h.build_seconds, h.front.present ? 1u : 0u, (unsigned long long)line_fails, (unsigned long long)from_line,
-                    (unsigned long long)h.front.n_unusable);
+                    (unsigned long long)h.front.n_unusable, (unsigned long long)h.front.n_walk);
         return fails ? 3 : 0;
     }
     if (mode == "batch" && argc >= 8) {

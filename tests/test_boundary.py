@@ -154,7 +154,7 @@ def test_builder_layout_self_consistent_on_host(host_check, prefix, w, skew):
     assert rep["n_fail"] == 0 and rep["line_fail"] == 0
     if w > 16 or (prefix, w) == (CF_YEAST, 12):
         assert rep["lines"] == 1 and rep["answered_from_line"] > 2.5 * rep["n_kmers"], rep  # of 3 queries per k-mer
-        assert (rep["lines_unusable"] > 0) == (w > 16)
+        assert (rep["walk_markers"] > 0) == (w > 16) and rep["lines_unusable"] == 0
 
 
 def test_builder_layout_matches_oracle_on_mixed_queries(host_check, tmp_path):
