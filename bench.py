@@ -293,11 +293,13 @@ def bench_projection(ix, us, d_recs, n, dev, torch, np, steps=5):
 
 
 # ------------------------------------------------------------------------------------------------ realistic skew (side line)
-def bench_realistic_skew(args, batch, dev, synth, torch, workload="s-human-rep"):
-    """point-query rates and the layout statistics of the repeat-family variant of the headline set (built, validated and freed here)"""
+def bench_realistic_skew(args, batch, dev, synth, torch, workload="s-human-rep", w=None):
+    """point-query rates and the layout statistics of a variant of the headline configuration (built, validated and freed here): the
+    repeat-family form of the set, or the same set at another minimizer length"""
     t0 = time.time()
+    w = w or args.w
     us2 = synth.make_unitig_set(workload, k=31, device=dev)
-    ix2, rep, rebuilds = synth.build_index_unique(us2, args.w, args.skew, args.seed, device=dev.index, on_device=not args.host_build)
+    ix2, rep, rebuilds = synth.build_index_unique(us2, w, args.skew, args.seed, device=dev.index, on_device=not args.host_build)
     st = ix2.line_stats()
     out = torch.empty(batch * 2, dtype=torch.int64, device=dev)
     cnt = torch.zeros(3, dtype=torch.int64, device=dev)
@@ -315,7 +317,8 @@ def bench_realistic_skew(args, batch, dev, synth, torch, workload="s-human-rep")
         torch.cuda.synchronize(dev)
         rates[name] = round(batch * 5 / (a.elapsed_time(b) / 1e3) / 1e6, 2)
         del q2
-    return {"workload": f"{workload}: {SHAPE[workload]}; {us2['rep_substitutions']} bases substituted so that no 31-mer of a copy repeats",
+    what = f"{workload}: {SHAPE[workload]}, m={w}" + (f"; {us2['rep_substitutions']} bases substituted so that no 31-mer of a copy repeats" if us2.get("rep_substitutions") else "")
+    return {"workload": what, "built_on": "gpu" if ix2.built_on_device() else "host",
             "M_kmers_per_s_one_gpu": rates, "validate_self": rep, "n_kmers": ix2.n_kmers(), "index_hbm_gb": round(ix2.device_bytes() / 1e9, 3),
             "lines": {"g": st["g"], "t": st["t"], "entries_per_line": round(st["entries_per_line"], 3), "frac_inline": round(st["frac_inline"], 4),
                       "frac_spilled": round(st["frac_spilled"], 4), "frac_heavy": round(st["frac_heavy"], 4)},
@@ -558,6 +561,9 @@ def main():
             # a side line, never the headline: the same shape with the repeat model of the configuration's description (repeat families with
             # per-copy divergence: bucket sizes form a continuum) instead of planted 16-mers -- does the layout hold up there?
             res["realistic_skew"] = bench_realistic_skew(args, batch, dev, synth, torch)
+            if args.w == 15:
+                # a second side line: the same set at minimizer length 19 (minimizer words beyond 32 bits: BBHash levels + hash-addressed lines, built on the GPU)
+                res["minimizer_19"] = bench_realistic_skew(args, batch, dev, synth, torch, workload="s-human", w=19)
         if n_gpus == 1 and not args.no_extra_mixes:
             # the step after k2u (get_ref_pos: PiscemUnitigTable occurrences -> MappedRefPos, src/index.rs:156-216) on the headline batch's
             # records: a synthetic tiling in which every unitig occurs once, occurrences packed into the minimal number of bits
